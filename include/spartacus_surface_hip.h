@@ -1,0 +1,285 @@
+/* spartacus_surface_hip.h - C-ABI of the MI355X SPARTACUS-Surface column solver.
+ *
+ * This is the drop-in boundary for ONE path of ecmwf/spartacus-surface: the
+ * per-column flux solver reached through
+ *     subroutine radsurf(config, canopy_props, sw_spectral_props,
+ *                        lw_spectral_props, bc_out, istartcol, iendcol,
+ *                        sw_norm_dir, sw_norm_diff, lw_internal, lw_norm)
+ * (reference: radsurf/radsurf_interface.F90:20-25, intents :48-59).
+ *
+ * Every struct below is a flat, plain-C view of one of the reference's Fortran
+ * derived types: dimensions plus raw pointers to the caller's own contiguous
+ * (allocatable) Fortran arrays.  A NULL pointer means "component not
+ * allocated", which is how the reference signals that a feature is off
+ * (e.g. flux_dn_layer_top => no flux profiles, radsurf_forest_sw.F90:583;
+ * roof_albedo_dir, radsurf_urban_sw.F90:631).  All reals are fp64
+ * (jprb = jprd, utilities/parkind1.F90:42-49), all integers 32 bit (jpim).
+ * Array index order is Fortran column-major with the spectral index first:
+ *     x(nspec, ncol)      ->  x[ispec + nspec*icol]
+ *     x(nspec, ntotlay)   ->  x[ispec + nspec*ilay]
+ * Layers are packed: column j owns layers istartlay[j] .. istartlay[j]+nlay[j]-1
+ * (1-based, exactly the Fortran values; radsurf_canopy_properties.F90:53-110).
+ *
+ * The Fortran side of the boundary is spartacus_surface_amd/fortran/
+ * radsurf_interface_hip.F90: a replacement "module radsurf_interface" with the
+ * identical radsurf signature that fills these structs with c_loc() pointers.
+ *
+ * No torch types, no C++ types, no device pointers in the host entry points.
+ */
+#ifndef SPARTACUS_SURFACE_HIP_H
+#define SPARTACUS_SURFACE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Maximum streams per hemisphere carried in the Legendre-Gauss tables.  The
+ * reference's shipped tests use 1, 2, 4 and 8 (test/.../config.nam). */
+#define SS_MAX_STREAMS 16
+
+/* Tile representation codes (radsurf_canopy_properties.F90:26-33). */
+enum {
+  SS_TILE_FLAT = 0,
+  SS_TILE_FOREST = 1,
+  SS_TILE_URBAN = 2,
+  SS_TILE_VEGETATED_URBAN = 3,
+  SS_TILE_SIMPLE_URBAN = 4,
+  SS_TILE_INFINITE_STREET = 5
+};
+
+/* Status codes returned by every entry point (0 = success).  The Fortran shim
+ * turns non-zero into radiation_abort, matching the reference's error
+ * behaviour (utilities/radiation_io.F90:46-54). */
+enum {
+  SS_OK = 0,
+  SS_ERR_NO_DEVICE = 1,          /* HIP runtime / MI355X not available        */
+  SS_ERR_UNSUPPORTED = 2,        /* (nstream, nregion) combination not built  */
+  SS_ERR_SIMPLE_URBAN_LAYERS = 3,/* radsurf_interface.F90:281-284             */
+  SS_ERR_VEG_DISABLED = 4,       /* radsurf_urban_sw.F90:275-277              */
+  SS_ERR_BAD_ARGUMENT = 5,
+  SS_ERR_HIP = 6,                /* a HIP call failed; see ss_last_error()    */
+  SS_ERR_TILE_NOT_ON_DEVICE = 7  /* tile types 4,5: single-layer Harman path,
+                                    SURVEY.md section 8(f) rank 4 (next)      */
+};
+
+/* legendre_gauss_type (radtool/radtool_legendre_gauss.F90:25-48). */
+typedef struct ss_legendre_gauss {
+  int32_t nstream;
+  int32_t pad_;
+  double mu[SS_MAX_STREAMS];
+  double sin_ang[SS_MAX_STREAMS];
+  double tan_ang[SS_MAX_STREAMS];
+  double weight[SS_MAX_STREAMS];
+  double hweight[SS_MAX_STREAMS];
+  double vweight[SS_MAX_STREAMS];
+  double vadjustment;
+  double vadjustment2;
+} ss_legendre_gauss;
+
+/* config_type: the members the solver reads (radsurf_config.F90:32-113). */
+typedef struct ss_config {
+  int32_t do_sw;
+  int32_t do_lw;
+  int32_t use_sw_direct_albedo;
+  int32_t do_vegetation;
+  int32_t do_urban;
+  int32_t n_vegetation_region_forest;
+  int32_t n_vegetation_region_urban;
+  int32_t nsw;                 /* nswinternal */
+  int32_t nlw;                 /* nlwinternal */
+  int32_t use_symmetric_vegetation_scale_forest;
+  int32_t use_symmetric_vegetation_scale_urban;
+  int32_t iverbose;
+  double vegetation_isolation_factor_forest;
+  double vegetation_isolation_factor_urban;
+  double min_vegetation_fraction;
+  double min_building_fraction;
+  ss_legendre_gauss lg_sw_forest;
+  ss_legendre_gauss lg_sw_urban;
+  ss_legendre_gauss lg_lw_forest;
+  ss_legendre_gauss lg_lw_urban;
+} ss_config;
+
+/* canopy_properties_type (radsurf_canopy_properties.F90:53-110).  The
+ * temperature members are not read by radsurf itself; they feed the optional
+ * calc_simple_spectrum_lw pre-step (radsurf_simple_spectrum.F90:41-66). */
+typedef struct ss_canopy {
+  int32_t ncol;
+  int32_t ntotlay;
+  const int32_t *nlay;             /* (ncol) */
+  const int32_t *istartlay;        /* (ncol) 1-based */
+  const int32_t *i_representation; /* (ncol) SS_TILE_* */
+  const double *cos_sza;           /* (ncol) */
+  const double *dz;                /* (ntotlay) */
+  const double *building_fraction; /* (ntotlay) */
+  const double *veg_fraction;      /* (ntotlay) */
+  const double *building_scale;    /* (ntotlay) */
+  const double *veg_scale;         /* (ntotlay) */
+  const double *veg_ext;           /* (ntotlay) */
+  const double *veg_fsd;           /* (ntotlay) */
+  const double *veg_contact_fraction; /* (ntotlay) */
+  const double *ground_temperature;    /* (ncol)    */
+  const double *roof_temperature;      /* (ntotlay) */
+  const double *wall_temperature;      /* (ntotlay) */
+  const double *clear_air_temperature; /* (ntotlay) */
+  const double *veg_temperature;       /* (ntotlay) */
+  const double *veg_air_temperature;   /* (ntotlay) */
+} ss_canopy;
+
+/* sw_spectral_properties_type (radsurf_sw_spectral_properties.F90:24-49). */
+typedef struct ss_sw_spectral {
+  int32_t nspec;
+  int32_t pad_;
+  const double *air_ext;            /* (nspec,ntotlay) */
+  const double *air_ssa;            /* (nspec,ntotlay) */
+  const double *veg_ssa;            /* (nspec,ntotlay) */
+  const double *ground_albedo;      /* (nspec,ncol)    */
+  const double *roof_albedo;        /* (nspec,ntotlay) */
+  const double *wall_albedo;        /* (nspec,ntotlay) */
+  const double *ground_albedo_dir;  /* (nspec,ncol)    */
+  const double *roof_albedo_dir;    /* (nspec,ntotlay) */
+  const double *wall_specular_frac; /* (nspec,ntotlay) */
+} ss_sw_spectral;
+
+/* lw_spectral_properties_type (radsurf_lw_spectral_properties.F90:24-57).
+ * The emission / Planck members are written by ss_calc_simple_spectrum_lw. */
+typedef struct ss_lw_spectral {
+  int32_t nspec;
+  int32_t pad_;
+  const double *air_ext;           /* (nspec,ntotlay) */
+  const double *air_ssa;           /* (nspec,ntotlay) */
+  const double *veg_ssa;           /* (nspec,ntotlay) */
+  double *clear_air_planck;        /* (nspec,ntotlay) */
+  double *veg_planck;              /* (nspec,ntotlay) */
+  double *veg_air_planck;          /* (nspec,ntotlay) */
+  const double *ground_emissivity; /* (nspec,ncol)    */
+  const double *roof_emissivity;   /* (nspec,ntotlay) */
+  const double *wall_emissivity;   /* (nspec,ntotlay) */
+  double *ground_emission;         /* (nspec,ncol)    */
+  double *roof_emission;           /* (nspec,ntotlay) */
+  double *wall_emission;           /* (nspec,ntotlay) */
+} ss_lw_spectral;
+
+/* boundary_conds_out_type (radsurf_boundary_conds_out.F90:24-39). */
+typedef struct ss_bc_out {
+  double *sw_albedo;     /* (nsw,ncol) */
+  double *sw_albedo_dir; /* (nsw,ncol) */
+  double *lw_emissivity; /* (nlw,ncol) */
+  double *lw_emission;   /* (nlw,ncol) */
+} ss_bc_out;
+
+/* canopy_flux_type (radsurf_canopy_flux.F90:27-91).  Member order is the
+ * order of declaration in the reference. */
+typedef struct ss_flux {
+  int32_t nspec;
+  int32_t ncol;
+  int32_t ntotlay;
+  int32_t pad_;
+  double *ground_dn;              /* (nspec,ncol)    */
+  double *ground_dn_dir;          /* (nspec,ncol)    */
+  double *ground_net;             /* (nspec,ncol)    */
+  double *top_dn;                 /* (nspec,ncol)    */
+  double *top_dn_dir;             /* (nspec,ncol)    */
+  double *top_net;                /* (nspec,ncol)    */
+  double *roof_in;                /* (nspec,ntotlay) */
+  double *roof_in_dir;            /* (nspec,ntotlay) */
+  double *roof_net;               /* (nspec,ntotlay) */
+  double *wall_in;                /* (nspec,ntotlay) */
+  double *wall_in_dir;            /* (nspec,ntotlay) */
+  double *wall_net;               /* (nspec,ntotlay) */
+  double *roof_sunlit_frac;       /* (ntotlay)       */
+  double *wall_sunlit_frac;       /* (ntotlay)       */
+  double *ground_sunlit_frac;     /* (ncol)          */
+  double *ground_vertical_diff;   /* (nspec,ncol)    */
+  double *clear_air_abs;          /* (nspec,ntotlay) */
+  double *veg_abs;                /* (nspec,ntotlay) */
+  double *veg_air_abs;            /* (nspec,ntotlay) */
+  double *veg_abs_dir;            /* (nspec,ntotlay) */
+  double *veg_sunlit_frac;        /* (ntotlay)       */
+  double *flux_dn_layer_top;      /* (nspec,ntotlay) */
+  double *flux_dn_dir_layer_top;  /* (nspec,ntotlay) */
+  double *flux_up_layer_top;      /* (nspec,ntotlay) */
+  double *flux_dn_layer_base;     /* (nspec,ntotlay) */
+  double *flux_dn_dir_layer_base; /* (nspec,ntotlay) */
+  double *flux_up_layer_base;     /* (nspec,ntotlay) */
+} ss_flux;
+
+#define SS_FLUX_NFIELDS 27
+
+/* --------------------------------------------------------------------------
+ * Host-buffer entry: replaces radsurf_interface::radsurf
+ * (radsurf/radsurf_interface.F90:20-313).  Same argument order and meaning.
+ * istartcol/iendcol are 1-based inclusive; pass 1 and canopy->ncol for the
+ * Fortran "optional absent" case (radsurf_interface.F90:86-96).  Flux objects
+ * may be NULL when the corresponding do_sw / do_lw is off.  Only slices
+ * (:,istartcol:iendcol) and the matching packed layer ranges of the outputs
+ * are written, exactly as the reference does, so disjoint column ranges may be
+ * processed by concurrent callers (driver/spartacus_surface_driver.F90:206-233);
+ * calls are serialised per device inside the library.
+ * The pointers are HOST pointers; the library stages them to HBM, runs the HIP
+ * kernels on the current device and copies the results back.
+ * -------------------------------------------------------------------------- */
+int spartacus_radsurf_hip(const ss_config *config, const ss_canopy *canopy,
+                          const ss_sw_spectral *sw, const ss_lw_spectral *lw,
+                          ss_bc_out *bc_out, int32_t istartcol, int32_t iendcol,
+                          ss_flux *sw_norm_dir, ss_flux *sw_norm_diff,
+                          ss_flux *lw_internal, ss_flux *lw_norm);
+
+/* --------------------------------------------------------------------------
+ * Device-resident plan API (what bench.py times and what a host model that
+ * keeps its fields on the GPU would call).  A plan owns device mirrors of all
+ * input and output arrays of one column set; upload / solve / download are
+ * separate so the timed region can start with inputs already in HBM.
+ * -------------------------------------------------------------------------- */
+typedef struct ss_plan ss_plan;
+
+/* Create a plan for the column set described by (config, canopy, sw, lw):
+ * classifies columns by tile type / layer count, allocates device mirrors,
+ * per-layer matrix scratch and the output arrays.  want_profiles != 0
+ * allocates the six SW / four LW layer-profile arrays (the stock driver always
+ * does: radsurf_canopy_flux.F90:114-118). */
+int ss_plan_create(ss_plan **plan, const ss_config *config,
+                   const ss_canopy *canopy, const ss_sw_spectral *sw,
+                   const ss_lw_spectral *lw, int32_t istartcol,
+                   int32_t iendcol, int32_t want_profiles);
+/* Copy (again) the input arrays host -> HBM. */
+int ss_plan_upload(ss_plan *plan, const ss_canopy *canopy,
+                   const ss_sw_spectral *sw, const ss_lw_spectral *lw);
+/* Optional pre-step calc_simple_spectrum_lw on device
+ * (radsurf/radsurf_simple_spectrum.F90:41-66). */
+int ss_plan_calc_simple_spectrum_lw(ss_plan *plan);
+/* One pass of the hot path over every column of the plan (asynchronous on the
+ * plan's stream). */
+int ss_plan_solve(ss_plan *plan);
+/* Block until the plan's stream is idle. */
+int ss_plan_synchronize(ss_plan *plan);
+/* Copy results HBM -> host arrays (only the plan's column / layer slices). */
+int ss_plan_download(ss_plan *plan, ss_bc_out *bc_out, ss_flux *sw_norm_dir,
+                     ss_flux *sw_norm_diff, ss_flux *lw_internal,
+                     ss_flux *lw_norm);
+/* Average device time (ms) of the kernels launched by the last ss_plan_solve,
+ * measured with HIP events on the plan's own stream; name selects a kernel
+ * family ("sw_layer", "lw_layer", "sw_column", "lw_column", "total"). */
+int ss_plan_last_kernel_ms(ss_plan *plan, const char *name, double *ms);
+/* Number of eigenproblems whose shifted-QR iteration hit the 30-iteration cap
+ * in the last solve (the reference silently ignores these:
+ * radtool_eigen_decomposition.F90:498-510, calc_matrices_sw_eig.F90:183). */
+int ss_plan_eigen_failures(ss_plan *plan, int64_t *count);
+/* Raw device pointer of an output / input mirror by name, e.g.
+ * "sw_norm_dir.ground_dn", "bc_out.sw_albedo" (for RCCL gathers). */
+int ss_plan_device_ptr(ss_plan *plan, const char *name, void **ptr,
+                       int64_t *nelem);
+int ss_plan_destroy(ss_plan *plan);
+
+/* Library / device information. */
+int ss_device_count(int32_t *count);
+int ss_set_device(int32_t device);
+const char *ss_last_error(void);
+const char *ss_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARTACUS_SURFACE_HIP_H */
