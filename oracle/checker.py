@@ -45,8 +45,26 @@ def have_oracle():
     return os.path.exists(ORACLE_LIB)
 
 
+def _raise_stack_limit():
+    """The reference keeps all per-column work arrays as Fortran automatics
+    (~10 MB per thread for the rami5 scenes: 14 bands x 12x12 x 62 layers), so
+    it needs what its users get from `ulimit -s unlimited`: raise the main
+    thread's soft stack limit and give OpenMP workers a large stack (the latter
+    must happen before libomp initialises, i.e. before the first CDLL)."""
+    import resource
+    os.environ.setdefault("OMP_STACKSIZE", "1G")
+    try:
+        soft, hard = resource.getrlimit(resource.RLIMIT_STACK)
+        if soft != resource.RLIM_INFINITY and (hard == resource.RLIM_INFINITY or hard > soft):
+            resource.setrlimit(resource.RLIMIT_STACK, (hard, hard))
+    except (ValueError, OSError):
+        pass
+
+
 def _load(path):
     if path not in _libs:
+        if path == REF_LIB:
+            _raise_stack_limit()
         _libs[path] = C.CDLL(path)
     return _libs[path]
 

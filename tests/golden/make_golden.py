@@ -1,0 +1,42 @@
+"""Generate the golden fixtures in tests/golden/ from the REAL reference.
+
+Run in the build container (needs /root/reference for the test inputs and the
+compiled reference in oracle/_ref):
+
+    python tests/golden/make_golden.py
+
+For every run of the reference's own `make test` that exercises the hot path
+(tests/cases.py) this freezes the solver inputs and the reference's fp64
+outputs (all members of bc_out and of the four canopy_flux objects, before
+scale/sum) into one compressed .npz.  The rami5 set is thinned to keep the
+repository small: every scene with diffuse illumination (real soil) and its
+first direct-beam angle with real and black soil.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import checker            # noqa: E402
+from tests import cases, fixture_io   # noqa: E402
+
+
+def main():
+    out_dir = os.path.dirname(os.path.abspath(__file__))
+    checker.build()
+    total = 0
+    for name, build in cases.all_cases(rami5="subset").items():
+        case = build()
+        outputs, _ = checker.run_ref(case["config"], case["canopy"], case["sw"], case["lw"],
+                                     want_profiles=True,
+                                     do_simple_spectrum=case["do_simple_spectrum"])
+        path = os.path.join(out_dir, name.replace("/", "__") + ".npz")
+        fixture_io.save_case(path, case, outputs, want_profiles=True)
+        total += os.path.getsize(path)
+        print("%-50s %7.1f KB" % (name, os.path.getsize(path) / 1024.0))
+    print("total %.2f MB" % (total / 1048576.0))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,57 @@
+"""The CPU restatement (oracle/spartacus_oracle.c) against the committed golden
+vectors, i.e. against outputs of the real reference on every input its own
+test suite ships (tests/golden/make_golden.py).  Runs without a GPU and without
+/root/reference."""
+import os
+
+import pytest
+
+from tests import fixture_io
+from tests.conftest import golden_files
+
+# The restatement keeps the reference's operation order, so it reproduces the
+# reference to rounding; 1e-11 leaves room for a different libm/compiler.
+TOL = 1.0e-11
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_oracle_matches_golden(path, checkers):
+    case, expected = fixture_io.load_case(path)
+    out, _ = checkers.run_oracle(case["config"], case["canopy"], case["sw"], case["lw"],
+                                 want_profiles=case["want_profiles"],
+                                 do_simple_spectrum=case["do_simple_spectrum"])
+    err, where = fixture_io.max_rel_error(fixture_io.flatten_outputs(out), expected)
+    assert err <= TOL, "max rel error %.3e at %s" % (err, where)
+
+
+def test_golden_set_is_complete():
+    names = {os.path.basename(p)[:-4] for p in golden_files()}
+    # every family of the reference's `make test`
+    for fam in ("simple__", "rami4pilps__", "urban__", "rami5__", "single_layer__"):
+        assert any(n.startswith(fam) for n in names), fam
+    assert len(names) >= 45
+
+
+def test_energy_conservation_on_goldens():
+    """Known-answer invariant of the reference (check_canopy_flux,
+    radsurf_canopy_flux.F90:465-542): ground + air + wall + roof + veg - top
+    net fluxes cancel."""
+    import numpy as np
+    for path in golden_files("simple__*"):
+        case, exp = fixture_io.load_case(path)
+        cp = case["canopy"]
+        for obj in ("sw_norm_dir", "sw_norm_diff", "lw_internal", "lw_norm"):
+            for j in range(cp.ncol):
+                l0 = cp.istartlay[j] - 1
+                lay = slice(l0, l0 + cp.nlay[j])
+                tot = exp[obj + ".ground_net"][j].sum() - exp[obj + ".top_net"][j].sum()
+                for k in ("clear_air_abs", "veg_abs", "veg_air_abs", "roof_net", "wall_net"):
+                    if cp.i_representation[j] == 0:
+                        continue
+                    if k in ("roof_net", "wall_net") and cp.i_representation[j] not in (2, 3):
+                        continue
+                    if k in ("veg_abs", "veg_air_abs") and cp.i_representation[j] not in (1, 3):
+                        continue
+                    tot += exp["%s.%s" % (obj, k)][lay].sum()
+                scale = max(1.0, abs(exp[obj + ".top_net"][j].sum()))
+                assert abs(tot) < 1e-7 * scale, (path, obj, j, tot)
