@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py - canopy columns/s of the SPARTACUS-Surface SW+LW column solver on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (radsurf: layer kernels + column kernels,
+SW and LW) over one batch of synthetic columns that is already resident in HBM.
+Workload at every N: BASELINE.json configs[2] = C3 of SURVEY.md section 8(d)
+(test/urban vegetated-urban column on 10 layers, 3 regions x 2 streams, 1 SW +
+1 LW band, 10^6 jittered columns per GPU, seed 12345).  With N > 1 every rank
+owns its own 10^6-column shard (weak scaling, no data-path collective); the only
+exchange is the final gather of the top-of-canopy boundary conditions
+(bc_out: albedos, emissivity, emission) over RCCL.
+
+Rank 0 prints one JSON line with the throughput, the roofline of the dominant
+kernel (HIP-event timing on the library's own stream) and the reference's CPU
+path timed on the host cores of the same box.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_PEAK_TFLOPS = 78.6     # vector = matrix fp64 peak
+
+
+def flops_per_column(case):
+    """Leading-order flop model of the reference's operation sequence per
+    (layer, band): F_sw = (74.4+8d)n^3 + 2/3(2n+d)^3 +
+    30d^3 + 22n^2 + 6n^2 d, F_lw = 70.4 n^3 + 30 n^2."""
+    cfg, cp = case["config"], case["canopy"]
+    L = float(cp.ntotlay) / max(1, cp.ncol)
+    tot = 0.0
+    for urban, share in ((False, float(np.mean(cp.i_representation == 1))),
+                         (True, float(np.mean(cp.i_representation != 1)))):
+        if share == 0.0:
+            continue
+        d = (cfg.n_vegetation_region_urban if urban else cfg.n_vegetation_region_forest) + 1
+        if cfg.do_sw:
+            n = d * (cfg.n_stream_sw_urban if urban else cfg.n_stream_sw_forest)
+            tot += share * cfg.nsw * L * ((74.4 + 8 * d) * n ** 3 + (2.0 / 3.0) * (2 * n + d) ** 3
+                                          + 30 * d ** 3 + 22 * n ** 2 + 6 * n ** 2 * d)
+        if cfg.do_lw:
+            n = d * (cfg.n_stream_lw_urban if urban else cfg.n_stream_lw_forest)
+            tot += share * cfg.nlw * L * (70.4 * n ** 3 + 30 * n ** 2)
+    return tot
+
+
+def cpu_baseline(ncol_sample):
+    """The REAL reference (oracle/_ref: Fortran compiled with flang -O2, OpenMP
+    block loop of its driver, nblocksize 16, schedule dynamic) on a bounded
+    sample of the same workload.  Falls back to the C port if _ref is absent."""
+    from spartacus_surface_amd import workloads
+    cores = min(16, os.cpu_count() or 1)
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    os.environ.setdefault("OMP_SCHEDULE", "dynamic")
+    from oracle import checker
+    case = workloads.c3_vegetated_urban(ncol=ncol_sample, seed=12345)
+    a = (case["config"], case["canopy"], case["sw"], case["lw"])
+    if checker.have_ref():
+        _, sec = checker.run_ref(*a, want_profiles=False, nblocksize=16, nrepeat=1)
+        kind = "reference"
+    else:
+        _, sec = checker.run_oracle(*a, want_profiles=False, nthreads=cores)
+        kind = "port"
+    return {"value": ncol_sample / sec, "unit": "columns/s", "cores": cores, "kind": kind,
+            "sample": "%d columns of the bench workload (C3, SW+LW), %.1f s, %s"
+                      % (ncol_sample, sec, "flang -O2 OpenMP dynamic nblocksize=16"
+                         if kind == "reference" else "gcc -O2 OpenMP C port")}
+
+
+class _DevArray:
+    """CUDA-array-interface view of a device array owned by the plan."""
+
+    def __init__(self, ptr, nelem):
+        self.__cuda_array_interface__ = {"shape": (nelem,), "typestr": "<f8",
+                                         "data": (ptr, False), "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--columns", type=int, default=1_000_000, help="columns per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=100_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from spartacus_surface_amd import radsurf, workloads
+    radsurf.load_library()
+    radsurf.set_device(local_rank)
+
+    case = workloads.c3_vegetated_urban(ncol=args.columns, seed=12345 + rank)
+    cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
+    plan = radsurf.Plan(cfg, cp, sw, lw, want_profiles=False)   # inputs now resident in HBM
+
+    gather = None
+    if world > 1:
+        names = ("bc_out.sw_albedo", "bc_out.sw_albedo_dir", "bc_out.lw_emissivity", "bc_out.lw_emission")
+        views = [torch.as_tensor(_DevArray(*plan.device_ptr(n)), device="cuda") for n in names]
+        outs = [torch.empty(world * v.numel(), dtype=torch.float64, device="cuda") for v in views]
+
+        def gather():
+            plan.synchronize()
+            for v, o in zip(views, outs):
+                dist.all_gather_into_tensor(o, v)
+
+    def step():
+        plan.solve()
+        if gather:
+            gather()
+
+    for _ in range(args.warmup):
+        step()
+    plan.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    fam_ms = {k: 0.0 for k in ("sw_layer", "sw_column", "lw_layer", "lw_column")}
+    fam_n = dict.fromkeys(fam_ms, 0)
+    for _ in range(args.steps):
+        step()
+        # HIP-event times of this step's launches (the query waits for the stream)
+        for k in fam_ms:
+            fam_ms[k] += plan.kernel_ms(k)
+            fam_n[k] += int(plan.kernel_ms(k + ".launches"))
+    plan.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    nfail = plan.eigen_failures()
+
+    if rank == 0:
+        total_cols = args.columns * world * args.steps
+        value = total_cols / elapsed
+        bytes_in, bytes_out = workloads.algorithmic_bytes_per_column(case)
+        bpc = bytes_in + bytes_out
+        dom = max(fam_ms, key=lambda k: fam_ms[k])
+        avg_ms = fam_ms[dom] / max(1, fam_n[dom])
+        cols_per_launch = args.columns * args.steps / max(1, fam_n[dom])
+        achieved = bpc * cols_per_launch / (avg_ms * 1e-3) / 1e9
+        fpc = flops_per_column(case)
+        kernel_total_ms = sum(fam_ms.values()) / args.steps
+        line = {
+            "metric": "canopy columns/s (SW+LW)", "value": value, "unit": "columns/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C3: test/urban vegetated-urban SW+LW, 3 regions x 2 streams "
+                                   "x 10 layers, 1 SW + 1 LW band, %d columns per GPU, seed 12345"
+                                   % args.columns,
+                       "columns_per_gpu": args.columns, "layers": 10, "nsw": cfg.nsw,
+                       "nlw": cfg.nlw, "parallelism": "columns sharded, %d GPU(s)" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_column": bpc, "avg_launch_ms": avg_ms,
+                         "launches_per_step": fam_n[dom] / args.steps,
+                         "note": "intensity ~%.0f flop/B: the path is fp64-VALU bound, "
+                                 "see 'fp64'" % (fpc / bpc)},
+            "fp64": {"achieved": fpc * args.columns / (kernel_total_ms * 1e-3) / 1e12,
+                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": fpc * args.columns / (kernel_total_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                     "flops_per_column_model": fpc},
+            "kernel_ms_per_step": {k: v / args.steps for k, v in fam_ms.items()},
+            "eigen_failures": nfail,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+        print(json.dumps(line), flush=True)
+    plan.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

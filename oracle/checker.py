@@ -21,6 +21,7 @@ from spartacus_surface_amd.types import BoundaryCondsOut, CanopyFlux
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_LIB = os.path.join(HERE, "_ref", "libspartacus_ref.so")
 ORACLE_LIB = os.path.join(HERE, "liboracle.so")
+ORACLE_QUAD_LIB = os.path.join(HERE, "liboracle_quad.so")
 
 _libs = {}
 
@@ -42,7 +43,7 @@ def have_ref():
 
 
 def have_oracle():
-    return os.path.exists(ORACLE_LIB)
+    return os.path.exists(ORACLE_LIB) and os.path.exists(ORACLE_QUAD_LIB)
 
 
 def _raise_stack_limit():
@@ -118,9 +119,11 @@ def run_ref(config, cp, sw, lw, want_profiles=True, do_simple_spectrum=False,
 
 
 def run_oracle(config, cp, sw, lw, want_profiles=True, do_simple_spectrum=False,
-               istartcol=1, iendcol=None, out=None, nthreads=1):
-    """Run the plain-C restatement.  Returns (outputs dict, seconds)."""
-    lib = _load(ORACLE_LIB)
+               istartcol=1, iendcol=None, out=None, nthreads=1, quad=False):
+    """Run the plain-C restatement.  Returns (outputs dict, seconds).
+    quad=True runs the same source compiled in IEEE binary128: the exact-
+    arithmetic yardstick against which rounding noise is measured."""
+    lib = _load(ORACLE_QUAD_LIB if quad else ORACLE_LIB)
     if iendcol is None:
         iendcol = cp.ncol
     if out is None:

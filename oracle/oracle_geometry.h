@@ -10,8 +10,8 @@
 
 /* calc_overlap_matrix_max_ran :28-73 (nreg = 2 or 3; also called with nreg=1
  * never - forests always have >= 2 regions) */
-static void or_overlap_matrix_max_ran(int nreg, double f_upper, double f_lower, double *om) {
-  double pair_cover = fmax(f_upper, f_lower);
+static void or_overlap_matrix_max_ran(int nreg, or_real f_upper, or_real f_lower, or_real *om) {
+  or_real pair_cover = OR_FMAX(f_upper, f_lower);
   E(om, 0, 0, nreg) = 1.0 - pair_cover;
   if (nreg == 2) {
     E(om, 0, 1, nreg) = pair_cover - f_upper;
@@ -33,15 +33,15 @@ static void or_overlap_matrix_max_ran(int nreg, double f_upper, double f_lower, 
  * (nreg x nlay+1) array works too: only the first nlay columns are read].
  * u_overlap(jupper,jlower,jlay): nreg x nreg x (nlay+1);
  * v_overlap(jlower,jupper,jlay): nreg x nreg x (nlay+1). */
-static void or_calc_overlap_matrices(int nlay, int nreg, const double *frac, int ldfrac,
-                                     double *u_overlap, double *v_overlap,
-                                     double frac_threshold) {
-  double om[9], frac_upper[3], frac_lower[3];
+static void or_calc_overlap_matrices(int nlay, int nreg, const or_real *frac, int ldfrac,
+                                     or_real *u_overlap, or_real *v_overlap,
+                                     or_real frac_threshold) {
+  or_real om[9], frac_upper[3], frac_lower[3];
   frac_lower[0] = 1.0;
   for (int r = 1; r < nreg; ++r) frac_lower[r] = 0.0;
   for (int jlay = 0; jlay <= nlay; ++jlay) {
-    double *u = u_overlap + (size_t)jlay * nreg * nreg;
-    double *v = v_overlap + (size_t)jlay * nreg * nreg;
+    or_real *u = u_overlap + (size_t)jlay * nreg * nreg;
+    or_real *v = v_overlap + (size_t)jlay * nreg * nreg;
     if (jlay >= nlay) {
       frac_upper[0] = 1.0;
       for (int r = 1; r < nreg; ++r) frac_upper[r] = 0.0;
@@ -66,14 +66,14 @@ static void or_calc_overlap_matrices(int nlay, int nreg, const double *frac, int
 
 /* calc_overlap_matrix_max_ran_urban :178-280.  om is nreg x (nreg+1),
  * first index upper layer, second lower layer (last = exposed roof). */
-static void or_overlap_matrix_max_ran_urban(int nreg, const double *fu, const double *fl,
-                                            double *om) {
-  double pair_cover;
+static void or_overlap_matrix_max_ran_urban(int nreg, const or_real *fu, const or_real *fl,
+                                            or_real *om) {
+  or_real pair_cover;
   if (nreg == 1) {
     E(om, 0, 0, 1) = fl[0];
     E(om, 0, 1, 1) = fl[1];
   } else if (nreg == 2) {
-    pair_cover = fmax(fu[1], fl[1]);
+    pair_cover = OR_FMAX(fu[1], fl[1]);
     if (pair_cover <= fl[0] + fl[1]) {
       E(om, 1, 2, 2) = 0.0;
       E(om, 0, 2, 2) = fl[2];
@@ -92,7 +92,7 @@ static void or_overlap_matrix_max_ran_urban(int nreg, const double *fu, const do
   } else {
     E(om, 1, 2, 3) = 0.0;
     E(om, 2, 1, 3) = 0.0;
-    pair_cover = fmax(fu[1] + fu[2], fl[1] + fl[2]);
+    pair_cover = OR_FMAX(fu[1] + fu[2], fl[1] + fl[2]);
     if (pair_cover <= fl[0] + fl[1] + fl[2]) {
       E(om, 1, 3, 3) = 0.0;
       E(om, 2, 3, 3) = 0.0;
@@ -133,17 +133,17 @@ static void or_overlap_matrix_max_ran_urban(int nreg, const double *fu, const do
 /* calc_overlap_matrices_urban :289-394.
  * u_overlap(jupper,jlower,jlay): nreg x (nreg+1) x (nlay+1)
  * v_overlap(jlower,jupper,jlay): (nreg+1) x nreg x (nlay+1) */
-static void or_calc_overlap_matrices_urban(int nlay, int nreg, const double *frac, int ldfrac,
-                                           double *u_overlap, double *v_overlap,
-                                           double frac_threshold) {
+static void or_calc_overlap_matrices_urban(int nlay, int nreg, const or_real *frac, int ldfrac,
+                                           or_real *u_overlap, or_real *v_overlap,
+                                           or_real frac_threshold) {
   const int nlo = nreg + 1;
-  double om[12], frac_upper[3], frac_lower[4];
-  double s0 = 0.0;
+  or_real om[12], frac_upper[3], frac_lower[4];
+  or_real s0 = 0.0;
   for (int r = 0; r < nreg; ++r) { frac_lower[r] = 0.0; s0 += E(frac, r, 0, ldfrac); }
   frac_lower[nreg] = s0;
   for (int jlay = 0; jlay <= nlay; ++jlay) {
-    double *u = u_overlap + (size_t)jlay * nreg * nlo;
-    double *v = v_overlap + (size_t)jlay * nlo * nreg;
+    or_real *u = u_overlap + (size_t)jlay * nreg * nlo;
+    or_real *v = v_overlap + (size_t)jlay * nlo * nreg;
     if (jlay >= nlay) {
       frac_upper[0] = 1.0;
       for (int r = 1; r < nreg; ++r) frac_upper[r] = 0.0;
@@ -165,7 +165,7 @@ static void or_calc_overlap_matrices_urban(int nlay, int nreg, const double *fra
     for (int r = 0; r < nreg; ++r) frac_lower[r] = frac_upper[r];
     /* jlay is 0-based here: Fortran "jlay < nlay" <=> jlay+1 < nlay */
     if (jlay + 1 < nlay) {
-      double sup = 0.0, slo = 0.0;
+      or_real sup = 0.0, slo = 0.0;
       for (int r = 0; r < nreg; ++r) { sup += E(frac, r, jlay + 1, ldfrac); slo += E(frac, r, jlay, ldfrac); }
       frac_lower[nreg] = sup - slo;
       if (frac_lower[nreg] < 0.0) {
@@ -173,7 +173,7 @@ static void or_calc_overlap_matrices_urban(int nlay, int nreg, const double *fra
         frac_lower[nreg] = 0.0;
       }
     } else if (jlay + 1 == nlay) {
-      double slo = 0.0;
+      or_real slo = 0.0;
       for (int r = 0; r < nreg; ++r) slo += E(frac, r, jlay, ldfrac);
       frac_lower[nreg] = 1.0 - slo;
     }
@@ -183,15 +183,15 @@ static void or_calc_overlap_matrices_urban(int nlay, int nreg, const double *fra
 /* calc_norm_perim_forest :30-116.  norm_perim is nreg x nlay. */
 static void or_calc_norm_perim_forest(const ss_config *config, int nlay, int nreg,
                                       const double *veg_fraction, const double *veg_scale,
-                                      double *norm_perim) {
-  const double iso = config->vegetation_isolation_factor_forest;
+                                      or_real *norm_perim) {
+  const or_real iso = config->vegetation_isolation_factor_forest;
   for (int k = 0; k < nreg * nlay; ++k) norm_perim[k] = 0.0;
   for (int jlay = 0; jlay < nlay; ++jlay) {
-    double *np = norm_perim + (size_t)jlay * nreg;
+    or_real *np = norm_perim + (size_t)jlay * nreg;
     if (nreg > 1) {
       if (veg_fraction[jlay] > config->min_vegetation_fraction) {
         if (config->use_symmetric_vegetation_scale_forest)
-          np[0] = 4.0 * veg_fraction[jlay] * fmax(0.0, 1.0 - veg_fraction[jlay]) / veg_scale[jlay];
+          np[0] = 4.0 * veg_fraction[jlay] * OR_FMAX(0.0, 1.0 - veg_fraction[jlay]) / veg_scale[jlay];
         else
           np[0] = 4.0 * veg_fraction[jlay] / veg_scale[jlay];
         if (nreg > 2) {
@@ -201,7 +201,7 @@ static void or_calc_norm_perim_forest(const ss_config *config, int nlay, int nre
             np[1] = (1.0 - iso) * 4.0 * (0.5 * veg_fraction[jlay])
                     * (1.0 - (0.5 * veg_fraction[jlay])) / veg_scale[jlay];
           else
-            np[1] = (1.0 - iso) * 4.0 * veg_fraction[jlay] / (sqrt(2.0) * veg_scale[jlay]);
+            np[1] = (1.0 - iso) * 4.0 * veg_fraction[jlay] / (OR_SQRT(2.0) * veg_scale[jlay]);
         } else {
           for (int r = 1; r < nreg; ++r) np[r] = 0.0;
         }
@@ -216,18 +216,18 @@ static void or_calc_norm_perim_urban(const ss_config *config, int nlay, int nreg
                                      const double *building_fraction,
                                      const double *building_scale, const double *veg_fraction,
                                      const double *veg_scale, const double *veg_contact_fraction,
-                                     double *norm_perim, double *norm_perim_wall) {
-  const double iso = config->vegetation_isolation_factor_urban;
+                                     or_real *norm_perim, or_real *norm_perim_wall) {
+  const or_real iso = config->vegetation_isolation_factor_urban;
   for (int k = 0; k < nreg * nlay; ++k) { norm_perim[k] = 0.0; norm_perim_wall[k] = 0.0; }
   for (int jlay = 0; jlay < nlay; ++jlay) {
-    double *np = norm_perim + (size_t)jlay * nreg;
-    double *npw = norm_perim_wall + (size_t)jlay * nreg;
+    or_real *np = norm_perim + (size_t)jlay * nreg;
+    or_real *npw = norm_perim_wall + (size_t)jlay * nreg;
     if (nreg > 1) {
       if (veg_fraction[jlay] > config->min_vegetation_fraction) {
         if (config->use_symmetric_vegetation_scale_urban)
           np[0] = 4.0 * veg_fraction[jlay]
-                  * fmax(0.0, 1.0 - veg_fraction[jlay] - building_fraction[jlay])
-                  / (fmax(config->min_building_fraction, 1.0 - building_fraction[jlay])
+                  * OR_FMAX(0.0, 1.0 - veg_fraction[jlay] - building_fraction[jlay])
+                  / (OR_FMAX(config->min_building_fraction, 1.0 - building_fraction[jlay])
                      * veg_scale[jlay]);
         else
           np[0] = 4.0 * veg_fraction[jlay] / veg_scale[jlay];
@@ -237,10 +237,10 @@ static void or_calc_norm_perim_urban(const ss_config *config, int nlay, int nreg
           if (config->use_symmetric_vegetation_scale_urban)
             np[1] = (1.0 - iso) * 4.0 * (0.5 * veg_fraction[jlay])
                     * (1.0 - (0.5 * veg_fraction[jlay]) - building_fraction[jlay])
-                    / (fmax(config->min_building_fraction, 1.0 - building_fraction[jlay])
+                    / (OR_FMAX(config->min_building_fraction, 1.0 - building_fraction[jlay])
                        * veg_scale[jlay]);
           else
-            np[1] = (1.0 - iso) * 4.0 * veg_fraction[jlay] / (sqrt(2.0) * veg_scale[jlay]);
+            np[1] = (1.0 - iso) * 4.0 * veg_fraction[jlay] / (OR_SQRT(2.0) * veg_scale[jlay]);
         } else {
           for (int r = 1; r < nreg; ++r) np[r] = 0.0;
         }

@@ -13,6 +13,33 @@
 #include <string.h>
 #include <float.h>
 
+/* Arithmetic type of the restatement.  Default: or_real = double (jprb = jprd,
+ * utilities/parkind1.F90:42-49) - the checker proper.  With -DORACLE_QUAD the
+ * same source is compiled in IEEE binary128 (liboracle_quad.so): an
+ * "exact-arithmetic" rendering of the reference's algorithm on the same fp64
+ * inputs and constants, used by the tests to measure how much of a difference
+ * between two fp64 implementations is the reference's own rounding noise. */
+#ifdef ORACLE_QUAD
+#include <quadmath.h>
+typedef __float128 or_real;
+#define OR_SQRT sqrtq
+#define OR_EXP expq
+#define OR_FABS fabsq
+#define OR_FMAX fmaxq
+#define OR_COPYSIGN copysignq
+#define OR_EPS FLT128_EPSILON
+#define OR_QR_CAP 120   /* converging to 1e-34 takes more sweeps than the fp64 cap of 30 */
+#else
+typedef double or_real;
+#define OR_SQRT sqrt
+#define OR_EXP exp
+#define OR_FABS fabs
+#define OR_FMAX fmax
+#define OR_COPYSIGN copysign
+#define OR_EPS DBL_EPSILON
+#define OR_QR_CAP 30    /* radtool_eigen_decomposition.F90:498 */
+#endif
+
 /* element (i,j) of a column-major matrix with leading dimension ld */
 #define E(a, i, j, ld) ((a)[(i) + (size_t)(j) * (ld)])
 
@@ -22,12 +49,12 @@
 #define OR_MAXBIG (2 * 48 + 3)
 
 /* Fortran sign(a,b) */
-static inline double or_sign(double a, double b) { return copysign(fabs(a), b); }
+static inline or_real or_sign(or_real a, or_real b) { return OR_COPYSIGN(OR_FABS(a), b); }
 
 /* ---- matrix products (radtool/radtool_matrix.F90) ---- */
 
 /* mat_x_mat :248-331 (dense branch): C = A*B, all m x m.  Loop order j2,j3,j1. */
-static void or_mat_x_mat(int m, const double *A, const double *B, double *C) {
+static void or_mat_x_mat(int m, const or_real *A, const or_real *B, or_real *C) {
   for (int k = 0; k < m * m; ++k) C[k] = 0.0;
   for (int j2 = 0; j2 < m; ++j2)
     for (int j3 = 0; j3 < m; ++j3)
@@ -36,52 +63,52 @@ static void or_mat_x_mat(int m, const double *A, const double *B, double *C) {
 }
 
 /* rect_mat_x_mat :335-374: C(k x m) = A(k x l) * B(l x m).  Order j2,j1,j3. */
-static void or_rect_mat_x_mat(int k, int l, int m, const double *A, const double *B, double *C) {
+static void or_rect_mat_x_mat(int k, int l, int m, const or_real *A, const or_real *B, or_real *C) {
   for (int j2 = 0; j2 < m; ++j2)
     for (int j1 = 0; j1 < k; ++j1) {
-      double s = 0.0;
+      or_real s = 0.0;
       for (int j3 = 0; j3 < l; ++j3) s += E(A, j1, j3, k) * E(B, j3, j2, l);
       E(C, j1, j2, k) = s;
     }
 }
 
 /* mat_x_vec :71-119 / rect_mat_x_vec :125-160: y(k) = A(k x l) x(l), lda given */
-static void or_rect_mat_x_vec(int k, int l, const double *A, int lda, const double *x, double *y) {
+static void or_rect_mat_x_vec(int k, int l, const or_real *A, int lda, const or_real *x, or_real *y) {
   for (int j1 = 0; j1 < k; ++j1) {
-    double s = 0.0;
+    or_real s = 0.0;
     for (int j2 = 0; j2 < l; ++j2) s += E(A, j1, j2, lda) * x[j2];
     y[j1] = s;
   }
 }
-static void or_mat_x_vec(int m, const double *A, const double *x, double *y) {
+static void or_mat_x_vec(int m, const or_real *A, const or_real *x, or_real *y) {
   or_rect_mat_x_vec(m, m, A, m, x, y);
 }
 
 /* ---- LU (no pivoting) (radtool_matrix.F90:982-1090) ---- */
 
 /* lu_factorization :982-1017 */
-static void or_lu_factorization(int m, const double *A, double *LU) {
-  memcpy(LU, A, sizeof(double) * (size_t)m * m);
+static void or_lu_factorization(int m, const or_real *A, or_real *LU) {
+  memcpy(LU, A, sizeof(or_real) * (size_t)m * m);
   for (int j2 = 0; j2 < m; ++j2) {
     for (int j1 = 0; j1 < j2; ++j1) {
-      double s = E(LU, j1, j2, m);
+      or_real s = E(LU, j1, j2, m);
       for (int j3 = 0; j3 < j1; ++j3) s -= E(LU, j1, j3, m) * E(LU, j3, j2, m);
       E(LU, j1, j2, m) = s;
     }
     for (int j1 = j2; j1 < m; ++j1) {
-      double s = E(LU, j1, j2, m);
+      or_real s = E(LU, j1, j2, m);
       for (int j3 = 0; j3 < j2; ++j3) s -= E(LU, j1, j3, m) * E(LU, j3, j2, m);
       E(LU, j1, j2, m) = s;
     }
     if (j2 != m - 1) {
-      double s = 1.0 / E(LU, j2, j2, m);
+      or_real s = 1.0 / E(LU, j2, j2, m);
       for (int j1 = j2 + 1; j1 < m; ++j1) E(LU, j1, j2, m) *= s;
     }
   }
 }
 
 /* lu_substitution :1024-1050 */
-static void or_lu_substitution(int m, const double *LU, const double *b, double *x) {
+static void or_lu_substitution(int m, const or_real *LU, const or_real *b, or_real *x) {
   for (int j = 0; j < m; ++j) x[j] = b[j];
   for (int j2 = 1; j2 < m; ++j2)
     for (int j1 = 0; j1 < j2; ++j1) x[j2] -= x[j1] * E(LU, j2, j1, m);
@@ -92,11 +119,11 @@ static void or_lu_substitution(int m, const double *LU, const double *b, double 
 }
 
 /* invert :1203-1231 = lu_factorization + lu_invert :1057-1090 (always generic) */
-static void or_invert(int m, const double *A, double *X) {
-  double LU[OR_MAXN * OR_MAXN];
+static void or_invert(int m, const or_real *A, or_real *X) {
+  or_real LU[OR_MAXN * OR_MAXN];
   or_lu_factorization(m, A, LU);
   for (int j3 = 0; j3 < m; ++j3) {
-    double *x = X + (size_t)j3 * m;
+    or_real *x = X + (size_t)j3 * m;
     for (int j2 = 0; j2 < m; ++j2) x[j2] = 0.0;
     x[j3] = 1.0;
     for (int j2 = 1; j2 < m; ++j2)
@@ -109,36 +136,36 @@ static void or_invert(int m, const double *A, double *X) {
 }
 
 /* solve_rect_mat :1119-1137: always generic LU; B, X are m x l */
-static void or_solve_rect_mat(int m, int l, const double *A, const double *B, double *X) {
-  double LU[OR_MAXBIG * OR_MAXBIG];
+static void or_solve_rect_mat(int m, int l, const or_real *A, const or_real *B, or_real *X) {
+  or_real LU[OR_MAXBIG * OR_MAXBIG];
   or_lu_factorization(m, A, LU);
   for (int j = 0; j < l; ++j) or_lu_substitution(m, LU, B + (size_t)j * m, X + (size_t)j * m);
 }
 
 /* solve_vec :1143-1168 with solve_vec_2 (Cramer) :779-795 and solve_vec_3
  * (explicit LU) :827-860 */
-static void or_solve_vec(int m, const double *A, const double *b, double *x) {
+static void or_solve_vec(int m, const or_real *A, const or_real *b, or_real *x) {
   if (m == 2) {
-    double inv_det = 1.0 / (E(A, 0, 0, 2) * E(A, 1, 1, 2) - E(A, 0, 1, 2) * E(A, 1, 0, 2));
-    double x0 = inv_det * (E(A, 1, 1, 2) * b[0] - E(A, 0, 1, 2) * b[1]);
-    double x1 = inv_det * (E(A, 0, 0, 2) * b[1] - E(A, 1, 0, 2) * b[0]);
+    or_real inv_det = 1.0 / (E(A, 0, 0, 2) * E(A, 1, 1, 2) - E(A, 0, 1, 2) * E(A, 1, 0, 2));
+    or_real x0 = inv_det * (E(A, 1, 1, 2) * b[0] - E(A, 0, 1, 2) * b[1]);
+    or_real x1 = inv_det * (E(A, 0, 0, 2) * b[1] - E(A, 1, 0, 2) * b[0]);
     x[0] = x0; x[1] = x1;
   } else if (m == 3) {
-    double L21 = E(A, 1, 0, 3) / E(A, 0, 0, 3);
-    double L31 = E(A, 2, 0, 3) / E(A, 0, 0, 3);
-    double U22 = E(A, 1, 1, 3) - L21 * E(A, 0, 1, 3);
-    double U23 = E(A, 1, 2, 3) - L21 * E(A, 0, 2, 3);
-    double L32 = (E(A, 2, 1, 3) - L31 * E(A, 0, 1, 3)) / U22;
-    double U33 = E(A, 2, 2, 3) - L31 * E(A, 0, 2, 3) - L32 * U23;
-    double y2 = b[1] - L21 * b[0];
-    double y3 = b[2] - L31 * b[0] - L32 * y2;
-    double x3 = y3 / U33;
-    double x2 = (y2 - U23 * x3) / U22;
-    double x1 = (b[0] - E(A, 0, 1, 3) * x2 - E(A, 0, 2, 3) * x3) / E(A, 0, 0, 3);
+    or_real L21 = E(A, 1, 0, 3) / E(A, 0, 0, 3);
+    or_real L31 = E(A, 2, 0, 3) / E(A, 0, 0, 3);
+    or_real U22 = E(A, 1, 1, 3) - L21 * E(A, 0, 1, 3);
+    or_real U23 = E(A, 1, 2, 3) - L21 * E(A, 0, 2, 3);
+    or_real L32 = (E(A, 2, 1, 3) - L31 * E(A, 0, 1, 3)) / U22;
+    or_real U33 = E(A, 2, 2, 3) - L31 * E(A, 0, 2, 3) - L32 * U23;
+    or_real y2 = b[1] - L21 * b[0];
+    or_real y3 = b[2] - L31 * b[0] - L32 * y2;
+    or_real x3 = y3 / U33;
+    or_real x2 = (y2 - U23 * x3) / U22;
+    or_real x1 = (b[0] - E(A, 0, 1, 3) * x2 - E(A, 0, 2, 3) * x3) / E(A, 0, 0, 3);
     x[0] = x1; x[1] = x2; x[2] = x3;
   } else {
-    double LU[OR_MAXN * OR_MAXN];
-    double tmp[OR_MAXN];
+    or_real LU[OR_MAXN * OR_MAXN];
+    or_real tmp[OR_MAXN];
     or_lu_factorization(m, A, LU);
     or_lu_substitution(m, LU, b, tmp);
     for (int j = 0; j < m; ++j) x[j] = tmp[j];
@@ -147,11 +174,11 @@ static void or_solve_vec(int m, const double *A, const double *b, double *x) {
 
 /* solve_mat :1175-1197 (m=2 Cramer :801-821, m=3 explicit LU :866-906, else
  * solve_mat_n :1096-1112).  B, X are m x m; X may not alias A or B. */
-static void or_solve_mat(int m, const double *A, const double *B, double *X) {
+static void or_solve_mat(int m, const or_real *A, const or_real *B, or_real *X) {
   if (m == 2 || m == 3) {
     for (int j = 0; j < m; ++j) or_solve_vec(m, A, B + (size_t)j * m, X + (size_t)j * m);
   } else {
-    double LU[OR_MAXN * OR_MAXN];
+    or_real LU[OR_MAXN * OR_MAXN];
     or_lu_factorization(m, A, LU);
     for (int j = 0; j < m; ++j) or_lu_substitution(m, LU, B + (size_t)j * m, X + (size_t)j * m);
   }
@@ -161,10 +188,10 @@ static void or_solve_mat(int m, const double *A, const double *B, double *X) {
  * One matrix, always fp64 (the reference's locals are jprd).  1-based index
  * macros keep the transcription line-for-line checkable.  Returns 0, or the
  * index of the eigenvalue at which the 30-iteration cap was hit (:498-510). */
-static int or_eigen_decomposition_real(int norder, const double *amat, double *eigenvalue,
-                                       double *eigenvector) {
-  const double Tol = DBL_EPSILON;
-  const double C1 = 0.4375, C2 = 0.5, C3 = 0.75, C4 = 0.95, C5 = 16.0, C6 = 256.0;
+static int or_eigen_decomposition_real(int norder, const or_real *amat, or_real *eigenvalue,
+                                       or_real *eigenvector) {
+  const or_real Tol = OR_EPS;
+  const or_real C1 = 0.4375, C2 = 0.5, C3 = 0.75, C4 = 0.95, C5 = 16.0, C6 = 256.0;
   const int n = norder;
 #define AB(i, j) abal[((i)-1) + (size_t)((j)-1) * n]
 #define EV(i, j) eigenvec[((i)-1) + (size_t)((j)-1) * n]
@@ -172,17 +199,17 @@ static int or_eigen_decomposition_real(int norder, const double *amat, double *e
 #define EVAL(i) eigenval[(i)-1]
 
   if (n > 2) {
-    double abal[OR_MAXN * OR_MAXN], eigenvec[OR_MAXN * OR_MAXN];
-    double eigenval[OR_MAXN], wkd[2 * OR_MAXN];
+    or_real abal[OR_MAXN * OR_MAXN], eigenvec[OR_MAXN * OR_MAXN];
+    or_real eigenval[OR_MAXN], wkd[2 * OR_MAXN];
     int ji, jj, jn, ka, kk, ll, lb = 0, lll, n1, n2, in, kkk;
-    double column, ff, gg, hh, pp = 0, qq = 0, rr = 0, tmp, rnorm, row, ss, scale, tt;
-    double uu, vv, ww, xx, yy, zz;
+    or_real column, ff, gg, hh, pp = 0, qq = 0, rr = 0, tmp, rnorm, row, ss, scale, tt;
+    or_real uu, vv, ww, xx, yy, zz;
     int not_finished, not_last, is_error = 0, ierr = 0;
 
     for (ji = 1; ji <= n; ++ji) EVAL(ji) = 0.0;
     for (ji = 0; ji < n * n; ++ji) eigenvec[ji] = 0.0;
     for (ji = 1; ji <= n; ++ji) EV(ji, ji) = 1.0;
-    memcpy(abal, amat, sizeof(double) * (size_t)n * n);
+    memcpy(abal, amat, sizeof(or_real) * (size_t)n * n);
     for (ji = 0; ji < 2 * n; ++ji) wkd[ji] = 0.0;
 
     rnorm = 0.0;
@@ -197,7 +224,7 @@ static int or_eigen_decomposition_real(int norder, const double *amat, double *e
       for (jj = kkk; jj >= 1; --jj) {
         row = 0.0;
         for (ji = 1; ji <= kk; ++ji)
-          if (ji != jj) row += fabs(AB(jj, ji));
+          if (ji != jj) row += OR_FABS(AB(jj, ji));
         if (row == 0.0) {
           WK(kk) = jj;
           /* :201 "if (ji /= kk)" is always true (ji == kk+1 after the loop) */
@@ -224,7 +251,7 @@ static int or_eigen_decomposition_real(int norder, const double *amat, double *e
       for (jj = lll; jj <= kk; ++jj) {
         column = 0.0;
         for (ji = ll; ji <= kk; ++ji)
-          if (ji != jj) column += fabs(AB(ji, jj));
+          if (ji != jj) column += OR_FABS(AB(ji, jj));
         if (column == 0.0) {
           WK(ll) = jj;
           if (jj != ll) {
@@ -254,8 +281,8 @@ static int or_eigen_decomposition_real(int norder, const double *amat, double *e
         row = 0.0;
         for (jj = ll; jj <= kk; ++jj)
           if (jj != ji) {
-            column += fabs(AB(jj, ji));
-            row += fabs(AB(ji, jj));
+            column += OR_FABS(AB(jj, ji));
+            row += OR_FABS(AB(ji, jj));
           }
         ff = 1.0;
         gg = row / C5;
@@ -278,13 +305,13 @@ static int or_eigen_decomposition_real(int norder, const double *amat, double *e
         hh = 0.0;
         WK(jn + n) = 0.0;
         scale = 0.0;
-        for (ji = jn; ji <= kk; ++ji) scale += fabs(AB(ji, jn - 1));
+        for (ji = jn; ji <= kk; ++ji) scale += OR_FABS(AB(ji, jn - 1));
         if (scale != 0.0) {
           for (ji = kk; ji >= jn; --ji) {
             WK(ji + n) = AB(ji, jn - 1) / scale;
             hh += WK(ji + n) * WK(ji + n);
           }
-          gg = -or_sign(sqrt(hh), WK(jn + n));
+          gg = -or_sign(OR_SQRT(hh), WK(jn + n));
           hh = hh - WK(jn + n) * gg;
           WK(jn + n) = WK(jn + n) - gg;
           hh = 1.0 / hh;
@@ -324,7 +351,7 @@ static int or_eigen_decomposition_real(int norder, const double *amat, double *e
     /* :397-408 */
     jn = 1;
     for (ji = 1; ji <= n; ++ji) {
-      for (jj = jn; jj <= n; ++jj) rnorm += fabs(AB(ji, jj));
+      for (jj = jn; jj <= n; ++jj) rnorm += OR_FABS(AB(ji, jj));
       jn = ji;
       if (ji < ll || ji > kk) EVAL(ji) = AB(ji, ji);
     }
@@ -343,9 +370,9 @@ static int or_eigen_decomposition_real(int norder, const double *amat, double *e
         for (ji = ll; ji <= jn; ++ji) {
           lb = jn + ll - ji;
           if (lb == ll) break;
-          ss = fabs(AB(lb - 1, lb - 1)) + fabs(AB(lb, lb));
+          ss = OR_FABS(AB(lb - 1, lb - 1)) + OR_FABS(AB(lb, lb));
           if (ss == 0.0) ss = rnorm;
-          if (fabs(AB(lb, lb - 1)) < Tol * ss) break;
+          if (OR_FABS(AB(lb, lb - 1)) < Tol * ss) break;
         }
         xx = AB(jn, jn);
         if (lb == jn) {
@@ -362,7 +389,7 @@ static int or_eigen_decomposition_real(int norder, const double *amat, double *e
           /* two eigenvalues found :449-496 */
           pp = (yy - xx) * C2;
           qq = pp * pp + ww;
-          zz = sqrt(fabs(qq));
+          zz = OR_SQRT(OR_FABS(qq));
           AB(jn, jn) = xx + tt;
           xx = AB(jn, jn);
           AB(n1, n1) = yy + tt;
@@ -371,7 +398,7 @@ static int or_eigen_decomposition_real(int norder, const double *amat, double *e
           EVAL(jn) = EVAL(n1);
           if (zz != 0.0) EVAL(jn) = xx - ww / zz;
           xx = AB(jn, n1);
-          rr = 1.0 / sqrt(xx * xx + zz * zz);
+          rr = 1.0 / OR_SQRT(xx * xx + zz * zz);
           pp = xx * rr;
           qq = zz * rr;
           for (jj = n1; jj <= n; ++jj) {
@@ -393,7 +420,7 @@ static int or_eigen_decomposition_real(int norder, const double *amat, double *e
           not_finished = 1;
           break;
         }
-        if (in == 30) {
+        if (in == OR_QR_CAP) {
           /* :498-510 no convergence */
           ierr = jn;
           is_error = 1;
@@ -404,7 +431,7 @@ static int or_eigen_decomposition_real(int norder, const double *amat, double *e
         if (in == 10 || in == 20) {
           tt = tt + xx;
           for (ji = ll; ji <= jn; ++ji) AB(ji, ji) = AB(ji, ji) - xx;
-          ss = fabs(AB(jn, n1)) + fabs(AB(n1, n2));
+          ss = OR_FABS(AB(jn, n1)) + OR_FABS(AB(n1, n2));
           xx = C3 * ss;
           yy = xx;
           ww = -C1 * ss * ss;
@@ -419,13 +446,13 @@ static int or_eigen_decomposition_real(int norder, const double *amat, double *e
           pp = (rr * ss - ww) / AB(ji + 1, ji) + AB(ji, ji + 1);
           qq = AB(ji + 1, ji + 1) - zz - rr - ss;
           rr = AB(ji + 2, ji + 1);
-          ss = 1.0 / (fabs(pp) + fabs(qq) + fabs(rr));
+          ss = 1.0 / (OR_FABS(pp) + OR_FABS(qq) + OR_FABS(rr));
           pp = pp * ss;
           qq = qq * ss;
           rr = rr * ss;
           if (ji == lb) break;
-          uu = fabs(AB(ji, ji - 1)) * (fabs(qq) + fabs(rr));
-          vv = fabs(pp) * (fabs(AB(ji - 1, ji - 1)) + fabs(zz) + fabs(AB(ji + 1, ji + 1)));
+          uu = OR_FABS(AB(ji, ji - 1)) * (OR_FABS(qq) + OR_FABS(rr));
+          vv = OR_FABS(pp) * (OR_FABS(AB(ji - 1, ji - 1)) + OR_FABS(zz) + OR_FABS(AB(ji + 1, ji + 1)));
           if (uu <= Tol * vv) break;
         }
         AB(ji + 2, ji) = 0.0;
@@ -433,26 +460,26 @@ static int or_eigen_decomposition_real(int norder, const double *amat, double *e
           AB(jj, jj - 2) = 0.0;
           AB(jj, jj - 3) = 0.0;
         }
-        /* :557-633 double QR step on rows ji..jn; note the loop bound is the
+        /* :557-633 or_real QR step on rows ji..jn; note the loop bound is the
          * value of ji on entry, while ji itself is reused inside */
         {
           const int ka_first = ji;
           for (ka = ka_first; ka <= n1; ++ka) {
             not_last = (ka != n1);
             if (ka == ka_first) {
-              ss = or_sign(sqrt(pp * pp + qq * qq + rr * rr), pp);
+              ss = or_sign(OR_SQRT(pp * pp + qq * qq + rr * rr), pp);
               if (lb != ka_first) AB(ka, ka - 1) = -AB(ka, ka - 1);
             } else {
               pp = AB(ka, ka - 1);
               qq = AB(ka + 1, ka - 1);
               rr = 0.0;
               if (not_last) rr = AB(ka + 2, ka - 1);
-              xx = fabs(pp) + fabs(qq) + fabs(rr);
+              xx = OR_FABS(pp) + OR_FABS(qq) + OR_FABS(rr);
               if (xx == 0.0) continue;
               pp = pp / xx;
               qq = qq / xx;
               rr = rr / xx;
-              ss = or_sign(sqrt(pp * pp + qq * qq + rr * rr), pp);
+              ss = or_sign(OR_SQRT(pp * pp + qq * qq + rr * rr), pp);
               AB(ka, ka - 1) = -ss * xx;
             }
             pp = pp + ss;
@@ -509,7 +536,7 @@ static int or_eigen_decomposition_real(int norder, const double *amat, double *e
           AB(jn, jn) = 1.0;
           for (ji = jn - 1; ji >= 1; --ji) {
             ww = AB(ji, ji) - EVAL(jn);
-            if (fabs(ww) < fabs(Tol * rnorm)) ww = or_sign(Tol * rnorm, ww);
+            if (OR_FABS(ww) < OR_FABS(Tol * rnorm)) ww = or_sign(Tol * rnorm, ww);
             rr = AB(ji, jn);
             for (jj = n2; jj <= jn - 1; ++jj) rr += AB(ji, jj) * AB(jj, jn);
             AB(ji, jn) = -rr / ww;
@@ -534,14 +561,14 @@ static int or_eigen_decomposition_real(int norder, const double *amat, double *e
       for (ji = ll; ji <= kk; ++ji)
         for (jj = 1; jj <= n; ++jj) EV(ji, jj) = EV(ji, jj) * WK(ji);
       for (ji = ll - 1; ji >= 1; --ji) {
-        jj = (int)lround(WK(ji));
+        jj = (int)(WK(ji) + 0.5);
         if (ji < jj)
           for (jn = 1; jn <= n; ++jn) {
             tmp = EV(ji, jn); EV(ji, jn) = EV(jj, jn); EV(jj, jn) = tmp;
           }
       }
       for (ji = kk + 1; ji <= n; ++ji) {
-        jj = (int)lround(WK(ji));
+        jj = (int)(WK(ji) + 0.5);
         if (ji != jj)
           for (jn = 1; jn <= n; ++jn) {
             tmp = EV(ji, jn); EV(ji, jn) = EV(jj, jn); EV(jj, jn) = tmp;
@@ -549,18 +576,18 @@ static int or_eigen_decomposition_real(int norder, const double *amat, double *e
       }
     }
     for (ji = 0; ji < n; ++ji) eigenvalue[ji] = eigenval[ji];
-    memcpy(eigenvector, eigenvec, sizeof(double) * (size_t)n * n);
+    memcpy(eigenvector, eigenvec, sizeof(or_real) * (size_t)n * n);
     return ierr;
   } else if (n == 2) {
     /* :770-803 closed form */
-    const double a11 = E(amat, 0, 0, 2), a21 = E(amat, 1, 0, 2);
-    const double a12 = E(amat, 0, 1, 2), a22 = E(amat, 1, 1, 2);
-    double discriminant = (a11 - a22) * (a11 - a22) + 4.0 * a12 * a21;
-    double half_sqrt_disc, rnorm;
+    const or_real a11 = E(amat, 0, 0, 2), a21 = E(amat, 1, 0, 2);
+    const or_real a12 = E(amat, 0, 1, 2), a22 = E(amat, 1, 1, 2);
+    or_real discriminant = (a11 - a22) * (a11 - a22) + 4.0 * a12 * a21;
+    or_real half_sqrt_disc, rnorm;
     int ierr = (discriminant < 0.0) ? 2 : 0;
     eigenvalue[0] = 0.5 * (a11 + a22);
     eigenvalue[1] = eigenvalue[0];
-    half_sqrt_disc = 0.5 * sqrt(discriminant);
+    half_sqrt_disc = 0.5 * OR_SQRT(discriminant);
     if (a11 >= a22) {
       eigenvalue[0] = eigenvalue[0] + half_sqrt_disc;
       eigenvalue[1] = eigenvalue[1] - half_sqrt_disc;
@@ -572,7 +599,7 @@ static int or_eigen_decomposition_real(int norder, const double *amat, double *e
     E(eigenvector, 1, 1, 2) = 1.0;
     if (a11 == a22 && (a21 == 0.0 || a12 == 0.0)) {
       /* precedence exactly as written in the reference :795-797 */
-      rnorm = 1.0 / (Tol * fabs(a11) + fabs(a21) + fabs(a12) + fabs(a22));
+      rnorm = 1.0 / (Tol * OR_FABS(a11) + OR_FABS(a21) + OR_FABS(a12) + OR_FABS(a22));
       E(eigenvector, 1, 0, 2) = a21 * rnorm;
       E(eigenvector, 0, 1, 2) = a12 * rnorm;
     } else {
@@ -593,10 +620,10 @@ static int or_eigen_decomposition_real(int norder, const double *amat, double *e
 }
 
 /* ---- schur_invert_sw (radtool/radtool_schur.F90:32-53) ---- */
-static void or_schur_invert_sw(int n0, int n1, const double *g0, const double *g1,
-                               const double *g2, const double *g3, double *g0i, double *g1i,
-                               double *g2i, double *g3i) {
-  double t1[OR_MAXN * OR_MAXN], t2[OR_MAXN * OR_MAXN], t3[OR_MAXN * OR_MAXN];
+static void or_schur_invert_sw(int n0, int n1, const or_real *g0, const or_real *g1,
+                               const or_real *g2, const or_real *g3, or_real *g0i, or_real *g1i,
+                               or_real *g2i, or_real *g3i) {
+  or_real t1[OR_MAXN * OR_MAXN], t2[OR_MAXN * OR_MAXN], t3[OR_MAXN * OR_MAXN];
   or_invert(n0, g0, g0i);
   /* g1i = invert(g1 - g2 * solve_mat(g1, g2)) */
   or_solve_mat(n1, g1, g2, t1);
@@ -614,13 +641,13 @@ static void or_schur_invert_sw(int n0, int n1, const double *g0, const double *g
 }
 
 /* ---- direct_diffuse_part (radtool_calc_matrices_sw_eig.F90:303-386) ---- */
-static void or_direct_diffuse_part(int ndiff, int ndir, const double *exp_lambda_dz,
-                                   const double *exp_eigenval_dir_dz, const double *g0,
-                                   const double *g1, const double *g2, const double *g3,
-                                   const double *g4, double *s_up, double *s_dn) {
+static void or_direct_diffuse_part(int ndiff, int ndir, const or_real *exp_lambda_dz,
+                                   const or_real *exp_eigenval_dir_dz, const or_real *g0,
+                                   const or_real *g1, const or_real *g2, const or_real *g3,
+                                   const or_real *g4, or_real *s_up, or_real *s_dn) {
   const int nb = 2 * ndiff + ndir;
-  static __thread double g_d[OR_MAXBIG * OR_MAXBIG];
-  double g_d2[OR_MAXN * OR_MAXBIG], cprime_dir[OR_MAXBIG * 3], rhs[OR_MAXBIG * 3];
+  static __thread or_real g_d[OR_MAXBIG * OR_MAXBIG];
+  or_real g_d2[OR_MAXN * OR_MAXBIG], cprime_dir[OR_MAXBIG * 3], rhs[OR_MAXBIG * 3];
   for (int k = 0; k < nb * nb; ++k) g_d[k] = 0.0;
   for (int j = 0; j < ndiff; ++j)
     for (int i = 0; i < ndiff; ++i) {
@@ -665,18 +692,18 @@ static void or_direct_diffuse_part(int ndiff, int ndir, const double *exp_lambda
  * (gamma1-gamma2)(gamma1+gamma2) and the diffuse R, T
  * (sw :180-221, lw :142-176).  Outputs kept for the callers. */
 typedef struct {
-  double lambda[OR_MAXN], exp_lambda_dz[OR_MAXN];
-  double g1[OR_MAXN * OR_MAXN], g2[OR_MAXN * OR_MAXN];
-  double g1_d[OR_MAXN * OR_MAXN], g2_d[OR_MAXN * OR_MAXN];
-  double cprime_upper[OR_MAXN * OR_MAXN], cprime_lower[OR_MAXN * OR_MAXN];
+  or_real lambda[OR_MAXN], exp_lambda_dz[OR_MAXN];
+  or_real g1[OR_MAXN * OR_MAXN], g2[OR_MAXN * OR_MAXN];
+  or_real g1_d[OR_MAXN * OR_MAXN], g2_d[OR_MAXN * OR_MAXN];
+  or_real cprime_upper[OR_MAXN * OR_MAXN], cprime_lower[OR_MAXN * OR_MAXN];
 } or_diffuse_t;
 
-static int or_diffuse_part(int n, double dz, const double *gamma1, const double *gamma2,
-                           double *reflectance, double *transmittance, or_diffuse_t *w) {
-  double gamma_diff[OR_MAXN * OR_MAXN], gamma_sum[OR_MAXN * OR_MAXN];
-  double gamma_product[OR_MAXN * OR_MAXN], eigenval_prod[OR_MAXN];
-  double eigenvec_prod[OR_MAXN * OR_MAXN], tmp_mat[OR_MAXN * OR_MAXN];
-  double t1[OR_MAXN * OR_MAXN], t2[OR_MAXN * OR_MAXN];
+static int or_diffuse_part(int n, or_real dz, const or_real *gamma1, const or_real *gamma2,
+                           or_real *reflectance, or_real *transmittance, or_diffuse_t *w) {
+  or_real gamma_diff[OR_MAXN * OR_MAXN], gamma_sum[OR_MAXN * OR_MAXN];
+  or_real gamma_product[OR_MAXN * OR_MAXN], eigenval_prod[OR_MAXN];
+  or_real eigenvec_prod[OR_MAXN * OR_MAXN], tmp_mat[OR_MAXN * OR_MAXN];
+  or_real t1[OR_MAXN * OR_MAXN], t2[OR_MAXN * OR_MAXN];
   const int nn = n * n;
   int ierr;
   for (int k = 0; k < nn; ++k) {
@@ -686,14 +713,14 @@ static int or_diffuse_part(int n, double dz, const double *gamma1, const double 
   or_mat_x_mat(n, gamma_diff, gamma_sum, gamma_product);
   ierr = or_eigen_decomposition_real(n, gamma_product, eigenval_prod, eigenvec_prod);
   for (int j = 0; j < n; ++j) {
-    w->lambda[j] = sqrt(fmax(0.0, eigenval_prod[j]));
-    w->exp_lambda_dz[j] = exp(-w->lambda[j] * dz);
+    w->lambda[j] = OR_SQRT(OR_FMAX(0.0, eigenval_prod[j]));
+    w->exp_lambda_dz[j] = OR_EXP(-w->lambda[j] * dz);
   }
   /* tmp_mat = -solve_mat(gamma_diff, eigenvec_prod) * diag(lambda) */
   or_solve_mat(n, gamma_diff, eigenvec_prod, tmp_mat);
   for (int j = 0; j < n; ++j)
     for (int i = 0; i < n; ++i) {
-      double t = -E(tmp_mat, i, j, n);
+      or_real t = -E(tmp_mat, i, j, n);
       t = t * w->lambda[j];
       E(w->g1, i, j, n) = E(eigenvec_prod, i, j, n) + t;
       E(w->g2, i, j, n) = E(eigenvec_prod, i, j, n) - t;
@@ -723,39 +750,39 @@ static int or_diffuse_part(int n, double dz, const double *gamma1, const double 
 }
 
 /* ---- calc_matrices_sw_eig (radtool_calc_matrices_sw_eig.F90:30-298) ---- */
-static int or_calc_matrices_sw_eig(int ndiff, int ndir, double dz, double mu0,
-                                   const double *gamma0, const double *gamma1,
-                                   const double *gamma2, const double *gamma3,
-                                   double *reflectance, double *transmittance, double *s_up,
-                                   double *s_dn, double *trans_dir, double *int_dir,
-                                   double *int_diff, double *int_dir_diff) {
+static int or_calc_matrices_sw_eig(int ndiff, int ndir, or_real dz, or_real mu0,
+                                   const or_real *gamma0, const or_real *gamma1,
+                                   const or_real *gamma2, const or_real *gamma3,
+                                   or_real *reflectance, or_real *transmittance, or_real *s_up,
+                                   or_real *s_dn, or_real *trans_dir, or_real *int_dir,
+                                   or_real *int_diff, or_real *int_dir_diff) {
   static __thread or_diffuse_t w;
   const int n = ndiff, nn = ndiff * ndiff;
-  double eigenval_dir[3], g0[9], g0_inv[9], g0e[9], exp_dir[3];
-  double gamma3_g0[OR_MAXN * 3], g3[OR_MAXN * 3], g4[OR_MAXN * 3];
-  double gamma1_d[OR_MAXN * OR_MAXN], gamma2_inv_gamma1_d[OR_MAXN * OR_MAXN];
-  double tmp_mat[OR_MAXN * OR_MAXN], t1[OR_MAXN * OR_MAXN];
-  double v1[OR_MAXN], v2[OR_MAXN];
-  double gamma0i[9], gamma1i[OR_MAXN * OR_MAXN], gamma2i[OR_MAXN * OR_MAXN];
-  double gamma3i[OR_MAXN * 3];
+  or_real eigenval_dir[3], g0[9], g0_inv[9], g0e[9], exp_dir[3];
+  or_real gamma3_g0[OR_MAXN * 3], g3[OR_MAXN * 3], g4[OR_MAXN * 3];
+  or_real gamma1_d[OR_MAXN * OR_MAXN], gamma2_inv_gamma1_d[OR_MAXN * OR_MAXN];
+  or_real tmp_mat[OR_MAXN * OR_MAXN], t1[OR_MAXN * OR_MAXN];
+  or_real v1[OR_MAXN], v2[OR_MAXN];
+  or_real gamma0i[9], gamma1i[OR_MAXN * OR_MAXN], gamma2i[OR_MAXN * OR_MAXN];
+  or_real gamma3i[OR_MAXN * 3];
   int ierr;
   (void)mu0;
 
   /* Sections 1-2 */
   ierr = or_diffuse_part(n, dz, gamma1, gamma2, reflectance, transmittance, &w);
 
-  /* Section 3 :223-229: trans_dir = g0 diag(exp(eigenval_dir*dz)) g0^-1 */
+  /* Section 3 :223-229: trans_dir = g0 diag(OR_EXP(eigenval_dir*dz)) g0^-1 */
   ierr += or_eigen_decomposition_real(ndir, gamma0, eigenval_dir, g0);
   or_invert(ndir, g0, g0_inv);
   for (int j = 0; j < ndir; ++j) {
-    exp_dir[j] = exp(eigenval_dir[j] * dz);
+    exp_dir[j] = OR_EXP(eigenval_dir[j] * dz);
     for (int i = 0; i < ndir; ++i) E(g0e, i, j, ndir) = E(g0, i, j, ndir) * exp_dir[j];
   }
   or_mat_x_mat(ndir, g0e, g0_inv, trans_dir);
 
   /* Section 4 :231-253 */
   or_rect_mat_x_mat(n, ndir, ndir, gamma3, g0, gamma3_g0);
-  memcpy(gamma1_d, gamma1, sizeof(double) * (size_t)nn);
+  memcpy(gamma1_d, gamma1, sizeof(or_real) * (size_t)nn);
   for (int jd = 0; jd < ndir; ++jd) {
     for (int jo = 0; jo < n; ++jo) E(gamma1_d, jo, jo, n) = E(gamma1, jo, jo, n) + eigenval_dir[jd];
     or_invert(n, gamma1_d, t1);
@@ -783,16 +810,16 @@ static int or_calc_matrices_sw_eig(int ndiff, int ndir, double dz, double mu0,
 }
 
 /* ---- calc_matrices_lw_eig (radtool_calc_matrices_lw_eig.F90:32-230) ---- */
-static int or_calc_matrices_lw_eig(int n, double dz, const double *gamma1, const double *gamma2,
-                                   const double *emiss_rate, double *reflectance,
-                                   double *transmittance, double *source, double *int_flux,
-                                   double *int_flux_source) {
+static int or_calc_matrices_lw_eig(int n, or_real dz, const or_real *gamma1, const or_real *gamma2,
+                                   const or_real *emiss_rate, or_real *reflectance,
+                                   or_real *transmittance, or_real *source, or_real *int_flux,
+                                   or_real *int_flux_source) {
   static __thread or_diffuse_t w;
   const int nn = n * n;
-  double gamma2_inv_gamma1[OR_MAXN * OR_MAXN], tmp_mat[OR_MAXN * OR_MAXN];
-  double t1[OR_MAXN * OR_MAXN];
-  double inv_gamma_b[OR_MAXN], inv_g1_inv_gamma_b[OR_MAXN], tmp_vec[OR_MAXN];
-  double cb_prime[OR_MAXN], v1[OR_MAXN];
+  or_real gamma2_inv_gamma1[OR_MAXN * OR_MAXN], tmp_mat[OR_MAXN * OR_MAXN];
+  or_real t1[OR_MAXN * OR_MAXN];
+  or_real inv_gamma_b[OR_MAXN], inv_g1_inv_gamma_b[OR_MAXN], tmp_vec[OR_MAXN];
+  or_real cb_prime[OR_MAXN], v1[OR_MAXN];
   int ierr = or_diffuse_part(n, dz, gamma1, gamma2, reflectance, transmittance, &w);
 
   /* Section 3 :178-195 */

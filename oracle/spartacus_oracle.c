@@ -22,8 +22,8 @@
 #include "oracle_radtool.h"
 #include "oracle_geometry.h"
 
-static const double Pi = 3.14159265358979323846;             /* radiation_constants.F90:24 */
-static const double StefanBoltzmann = 5.67037321e-8;         /* radiation_constants.F90:26 */
+static const or_real Pi = 3.14159265358979323846;             /* radiation_constants.F90:24 */
+static const or_real StefanBoltzmann = 5.67037321e-8;         /* radiation_constants.F90:26 */
 
 #define MAXREG 3
 #define MAXS SS_MAX_STREAMS
@@ -32,17 +32,17 @@ static const double StefanBoltzmann = 5.67037321e-8;         /* radiation_consta
  * (radsurf_forest_sw.F90:107-199, radsurf_urban_sw.F90:112-210). */
 typedef struct {
   int n, nb, nlay;             /* n = nreg*ns, nb = "below" order */
-  double *trans_diff, *ref_diff, *ref_dir, *trans_dir_diff, *trans_dir_dir;
-  double *int_diff, *int_dir, *int_dir_diff;
-  double *a_above, *d_above, *a_below, *d_below, *denominator;
-  double *source_lay, *int_source, *source_above, *source_below;   /* LW */
-  double *frac, *norm_perim, *norm_perim_wall, *u_overlap, *v_overlap;
-  double *od_scaling, *f_wall, *f_wall_dir_clear;
-  double *emiss_reg, *emiss_air, *emiss_veg, *emiss_wall;
+  or_real *trans_diff, *ref_diff, *ref_dir, *trans_dir_diff, *trans_dir_dir;
+  or_real *int_diff, *int_dir, *int_dir_diff;
+  or_real *a_above, *d_above, *a_below, *d_below, *denominator;
+  or_real *source_lay, *int_source, *source_above, *source_below;   /* LW */
+  or_real *frac, *norm_perim, *norm_perim_wall, *u_overlap, *v_overlap;
+  or_real *od_scaling, *f_wall, *f_wall_dir_clear;
+  or_real *emiss_reg, *emiss_air, *emiss_veg, *emiss_wall;
 } or_work_t;
 
-static double *dalloc(size_t n) {
-  double *p = (double *)calloc(n ? n : 1, sizeof(double));
+static or_real *dalloc(size_t n) {
+  or_real *p = (or_real *)calloc(n ? n : 1, sizeof(or_real));
   if (!p) { fprintf(stderr, "oracle: out of memory\n"); abort(); }
   return p;
 }
@@ -121,19 +121,19 @@ static void flux_zero(ss_flux *f, int icol, int l0, int nlay) {
  * radsurf_forest_lw.F90:244-248, urban radsurf_urban_sw.F90:284-291 */
 static void region_fractions(int is_urban, int is_lw, int nreg, int nlay,
                              const double *veg_fraction, const double *building_fraction,
-                             double *frac) {
+                             or_real *frac) {
   for (int l = 0; l < nlay; ++l) {
-    double *fr = frac + (size_t)l * nreg;
+    or_real *fr = frac + (size_t)l * nreg;
     if (!is_urban) {
       fr[0] = 1.0 - veg_fraction[l];
       for (int r = 1; r < nreg; ++r)
-        fr[r] = (is_lw ? (1.0 - fr[0]) : veg_fraction[l]) / (double)(nreg - 1);
+        fr[r] = (is_lw ? (1.0 - fr[0]) : veg_fraction[l]) / (or_real)(nreg - 1);
     } else {
       fr[0] = 1.0 - building_fraction[l];
       if (nreg > 1) {
-        fr[0] = fmax(0.0, fr[0] - veg_fraction[l]);
+        fr[0] = OR_FMAX(0.0, fr[0] - veg_fraction[l]);
         for (int r = 1; r < nreg; ++r)
-          fr[r] = fmax(0.0, 1.0 - building_fraction[l] - fr[0]) / (double)(nreg - 1);
+          fr[r] = OR_FMAX(0.0, 1.0 - building_fraction[l] - fr[0]) / (or_real)(nreg - 1);
       }
     }
   }
@@ -144,8 +144,8 @@ static void region_fractions(int is_urban, int is_lw, int nreg, int nlay,
 /* f_exchange (radsurf_forest_sw.F90:299-321 and the identical blocks of the
  * other three solvers).  Note the use of norm_perim(jreg) after the loop, i.e.
  * jreg == nreg. */
-static void exchange_rates(int nreg, const double *frac, const double *norm_perim,
-                           double min_veg, double *f_exchange) {
+static void exchange_rates(int nreg, const or_real *frac, const or_real *norm_perim,
+                           or_real min_veg, or_real *f_exchange) {
   for (int k = 0; k < nreg * nreg; ++k) f_exchange[k] = 0.0;
   for (int jreg = 0; jreg < nreg - 1; ++jreg) {
     if (frac[jreg] <= min_veg || frac[jreg + 1] <= min_veg) {
@@ -170,8 +170,8 @@ static void exchange_rates(int nreg, const double *frac, const double *norm_peri
 /* (U (x) I_ns) applied from the left: rect_expandedmat_x_mat
  * (radtool_matrix.F90:505-550).  A is m x o, B is (o*s) x p with leading
  * dimension ldb, C is (m*s) x p. */
-static void expandedmat_x_mat(int m, int o, int s, int p, const double *A, const double *B,
-                              int ldb, double *C) {
+static void expandedmat_x_mat(int m, int o, int s, int p, const or_real *A, const or_real *B,
+                              int ldb, or_real *C) {
   const int ldc = m * s;
   for (int k = 0; k < ldc * p; ++k) C[k] = 0.0;
   for (int j1 = 0; j1 < m; ++j1)
@@ -186,8 +186,8 @@ static void expandedmat_x_mat(int m, int o, int s, int p, const double *A, const
 
 /* rect_mat_x_expandedmat (radtool_matrix.F90:556-601): A is p x (m*s),
  * B is m x o, C is p x (o*s) */
-static void mat_x_expandedmat(int m, int o, int s, int p, const double *A, const double *B,
-                              double *C) {
+static void mat_x_expandedmat(int m, int o, int s, int p, const or_real *A, const or_real *B,
+                              or_real *C) {
   for (int k = 0; k < p * o * s; ++k) C[k] = 0.0;
   for (int j2 = 0; j2 < o; ++j2)
     for (int j3 = 0; j3 < m; ++j3)
@@ -200,7 +200,7 @@ static void mat_x_expandedmat(int m, int o, int s, int p, const double *A, const
 }
 
 /* rect_expandedmat_x_vec (radtool_matrix.F90:608-649): A m x k, b (k*s), y (m*s) */
-static void expandedmat_x_vec(int m, int k, int s, const double *A, const double *b, double *y) {
+static void expandedmat_x_vec(int m, int k, int s, const or_real *A, const or_real *b, or_real *y) {
   for (int i = 0; i < m * s; ++i) y[i] = 0.0;
   for (int j1 = 0; j1 < m; ++j1)
     for (int j3 = 0; j3 < k; ++j3)
@@ -212,11 +212,11 @@ static void expandedmat_x_vec(int m, int k, int s, const double *A, const double
 
 /* Copy an (nsub x msub) result into the sub-block starting at (r0,c0) of a
  * zeroed (ld x *) matrix */
-static void put_block(double *dst, int ld, int r0, int c0, const double *src, int nsub, int msub) {
+static void put_block(or_real *dst, int ld, int r0, int c0, const or_real *src, int nsub, int msub) {
   for (int j = 0; j < msub; ++j)
     for (int i = 0; i < nsub; ++i) E(dst, r0 + i, c0 + j, ld) = E(src, i, j, nsub);
 }
-static void get_block(const double *src, int ld, int r0, int c0, double *dst, int nsub, int msub) {
+static void get_block(const or_real *src, int ld, int r0, int c0, or_real *dst, int nsub, int msub) {
   for (int j = 0; j < msub; ++j)
     for (int i = 0; i < nsub; ++i) E(dst, i, j, nsub) = E(src, r0 + i, c0 + j, ld);
 }
@@ -224,21 +224,21 @@ static void get_block(const double *src, int ld, int r0, int c0, double *dst, in
 /* od_scaling / ext_reg / ssa_reg [/ planck_reg] for one layer and band
  * (radsurf_forest_sw.F90:277-297, radsurf_forest_lw.F90:278-300 and the urban
  * equivalents).  od[r] valid for r = 1..nreg-1. */
-static void region_optics(int nreg, double air_ext, double air_ssa, double veg_ext, double veg_ssa,
-                          double veg_fsd, double *od, double *ext_reg, double *ssa_reg) {
+static void region_optics(int nreg, or_real air_ext, or_real air_ssa, or_real veg_ext, or_real veg_ssa,
+                          or_real veg_fsd, or_real *od, or_real *ext_reg, or_real *ssa_reg) {
   ext_reg[0] = air_ext;
   ssa_reg[0] = air_ssa;
   if (nreg == 2) {
     ext_reg[1] = air_ext + veg_ext;
-    ssa_reg[1] = (ext_reg[0] * ssa_reg[0] + veg_ext * veg_ssa) / fmax(ext_reg[1], 1.0e-8);
+    ssa_reg[1] = (ext_reg[0] * ssa_reg[0] + veg_ext * veg_ssa) / OR_FMAX(ext_reg[1], 1.0e-8);
     od[1] = 1.0;
   } else if (nreg == 3) {
-    od[1] = exp(-veg_fsd * (1.0 + 0.5 * veg_fsd * (1.0 + 0.5 * veg_fsd)));
+    od[1] = OR_EXP(-veg_fsd * (1.0 + 0.5 * veg_fsd * (1.0 + 0.5 * veg_fsd)));
     od[2] = 2.0 - od[1];
     ext_reg[1] = air_ext + od[1] * veg_ext;
     ext_reg[2] = air_ext + od[2] * veg_ext;
-    ssa_reg[1] = (ext_reg[0] * ssa_reg[0] + od[1] * veg_ext * veg_ssa) / fmax(ext_reg[1], 1.0e-8);
-    ssa_reg[2] = (ext_reg[0] * ssa_reg[0] + od[2] * veg_ext * veg_ssa) / fmax(ext_reg[2], 1.0e-8);
+    ssa_reg[1] = (ext_reg[0] * ssa_reg[0] + od[1] * veg_ext * veg_ssa) / OR_FMAX(ext_reg[1], 1.0e-8);
+    ssa_reg[2] = (ext_reg[0] * ssa_reg[0] + od[2] * veg_ext * veg_ssa) / OR_FMAX(ext_reg[2], 1.0e-8);
   }
 }
 
@@ -248,7 +248,7 @@ static void region_optics(int nreg, double air_ext, double air_ssa, double veg_e
  * icol, l0 0-based (l0 = istartlay-1).
  * ======================================================================= */
 static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nreg, int nlay,
-                    int icol, int l0, const ss_legendre_gauss *lg, double cos_sza_in,
+                    int icol, int l0, const ss_legendre_gauss *lg, or_real cos_sza_in,
                     const ss_canopy *cp, const ss_sw_spectral *sp, const double *ground_albedo_diff,
                     const double *ground_albedo_dir, double *top_albedo_diff, double *top_albedo_dir,
                     ss_flux *fdir, ss_flux *fdiff) {
@@ -271,19 +271,19 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
 
   /* urban: corrected cosine used everywhere (radsurf_urban_sw.F90:268);
    * forest: clamp only inside tan0 (radsurf_forest_sw.F90:241) */
-  const double cos_sza = is_urban ? fmax(cos_sza_in, 1.0e-6) : cos_sza_in;
-  double sin0 = 0.0, tan0;
-  double roof_fraction[512], non_building_fraction[513];
+  const or_real cos_sza = is_urban ? OR_FMAX(cos_sza_in, 1.0e-6) : cos_sza_in;
+  or_real sin0 = 0.0, tan0;
+  or_real roof_fraction[512], non_building_fraction[513];
   int itransp = 0;
 
   if (is_urban && do_vegetation && !cfg->do_vegetation) return SS_ERR_VEG_DISABLED;
   if (nlay > 511) return SS_ERR_BAD_ARGUMENT;
 
   if (is_urban) {
-    sin0 = sqrt(1.0 - cos_sza * cos_sza);
+    sin0 = OR_SQRT(1.0 - cos_sza * cos_sza);
     tan0 = sin0 / cos_sza;
   } else {
-    tan0 = sqrt(1.0 - cos_sza * cos_sza) / fmax(cos_sza, 1.0e-6);
+    tan0 = OR_SQRT(1.0 - cos_sza * cos_sza) / OR_FMAX(cos_sza, 1.0e-6);
   }
 
   work_alloc(&w, nreg, ns, nlay, is_urban);
@@ -294,16 +294,16 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
     roof_fraction[nlay] = 0.0;
     roof_fraction[nlay - 1] = building_fraction[nlay - 1];
     for (int l = 0; l < nlay - 1; ++l)
-      roof_fraction[l] = fmax(0.0, building_fraction[l] - building_fraction[l + 1]);
+      roof_fraction[l] = OR_FMAX(0.0, building_fraction[l] - building_fraction[l + 1]);
     non_building_fraction[nlay] = 1.0;
     for (int l = 0; l < nlay; ++l) non_building_fraction[l] = 1.0 - building_fraction[l];
   }
 
   /* most transparent band: minloc(sum(air_ext*dz)) :253 */
   {
-    double best = 0.0;
+    or_real best = 0.0;
     for (int b = 0; b < nsw; ++b) {
-      double od = 0.0;
+      or_real od = 0.0;
       for (int l = 0; l < nlay; ++l) od += SPEC(sp->air_ext, b, l) * dz[l];
       if (b == 0 || od < best) { best = od; itransp = b; }
     }
@@ -328,20 +328,20 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
    * apart from air_ext(itransp); it is evaluated inside band itransp */
 
   for (int jb = 0; jb < nsw; ++jb) {
-    double gamma0[9], gamma1[OR_MAXN * OR_MAXN], gamma2[OR_MAXN * OR_MAXN], gamma3[OR_MAXN * 3];
-    double f_exchange[9], ext_reg[3], ssa_reg[3];
-    double sub0[9], sub1[OR_MAXN * OR_MAXN], sub2[OR_MAXN * OR_MAXN], sub3[OR_MAXN * 3];
-    double oR[OR_MAXN * OR_MAXN], oT[OR_MAXN * OR_MAXN], oSu[OR_MAXN * 3], oSd[OR_MAXN * 3];
-    double oE[9], oId[9], oIf[OR_MAXN * OR_MAXN], oIdf[OR_MAXN * 3];
+    or_real gamma0[9], gamma1[OR_MAXN * OR_MAXN], gamma2[OR_MAXN * OR_MAXN], gamma3[OR_MAXN * 3];
+    or_real f_exchange[9], ext_reg[3], ssa_reg[3];
+    or_real sub0[9], sub1[OR_MAXN * OR_MAXN], sub2[OR_MAXN * OR_MAXN], sub3[OR_MAXN * 3];
+    or_real oR[OR_MAXN * OR_MAXN], oT[OR_MAXN * OR_MAXN], oSu[OR_MAXN * 3], oSd[OR_MAXN * 3];
+    or_real oE[9], oId[9], oIf[OR_MAXN * OR_MAXN], oIdf[OR_MAXN * 3];
 
     /* ---- Section 3: first loop over layers ---- */
     for (int jlay = 0; jlay < nlay; ++jlay) {
-      const double *frac = w.frac + (size_t)jlay * nreg;
-      const double *norm_perim = w.norm_perim + (size_t)jlay * nreg;
-      double *od = w.od_scaling + (size_t)jlay * (MAXREG + 1);
-      double *f_wall = w.f_wall + (size_t)jlay * nreg;
-      double wall_ext = 0.0, wall_factor = 0.0;
-      const double air_ext = SPEC(sp->air_ext, jb, jlay), air_ssa = SPEC(sp->air_ssa, jb, jlay);
+      const or_real *frac = w.frac + (size_t)jlay * nreg;
+      const or_real *norm_perim = w.norm_perim + (size_t)jlay * nreg;
+      or_real *od = w.od_scaling + (size_t)jlay * (MAXREG + 1);
+      or_real *f_wall = w.f_wall + (size_t)jlay * nreg;
+      or_real wall_ext = 0.0, wall_factor = 0.0;
+      const or_real air_ext = SPEC(sp->air_ext, jb, jlay), air_ssa = SPEC(sp->air_ssa, jb, jlay);
 
       region_optics(nreg, air_ext, air_ssa, do_vegetation ? veg_ext[jlay] : 0.0,
                     do_vegetation ? SPEC(sp->veg_ssa, jb, jlay) : 0.0,
@@ -351,7 +351,7 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
       for (int r = 0; r < nreg; ++r) f_wall[r] = 0.0;
       if (is_urban) {
         /* radsurf_urban_sw.F90:395-418 */
-        const double *npw = w.norm_perim_wall + (size_t)jlay * nreg;
+        const or_real *npw = w.norm_perim_wall + (size_t)jlay * nreg;
         for (int r = 0; r < nreg; ++r) {
           if (frac[r] <= cfg->min_vegetation_fraction) f_wall[r] = 0.0;
           else f_wall[r] = npw[r] / (Pi * frac[r]);
@@ -359,7 +359,7 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
         if (non_building_fraction[jlay] <= cfg->min_building_fraction) {
           w.f_wall_dir_clear[jlay] = 0.0;
         } else {
-          double s = 0.0;
+          or_real s = 0.0;
           for (int r = 0; r < nreg; ++r) s += npw[r];
           w.f_wall_dir_clear[jlay] = s / (Pi * non_building_fraction[jlay]);
         }
@@ -420,11 +420,11 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
 
       /* ---- Section 3c: layer matrices, 3-way branch (:408-455 / :520-583) ---- */
       {
-        double *Rl = w.ref_diff + (size_t)jlay * n * n, *Tl = w.trans_diff + (size_t)jlay * n * n;
-        double *Sul = w.ref_dir + (size_t)jlay * n * d, *Sdl = w.trans_dir_diff + (size_t)jlay * n * d;
-        double *El = w.trans_dir_dir + (size_t)jlay * d * d;
-        double *Idl = w.int_dir + (size_t)jlay * d * d, *Ifl = w.int_diff + (size_t)jlay * n * n;
-        double *Idfl = w.int_dir_diff + (size_t)jlay * n * d;
+        or_real *Rl = w.ref_diff + (size_t)jlay * n * n, *Tl = w.trans_diff + (size_t)jlay * n * n;
+        or_real *Sul = w.ref_dir + (size_t)jlay * n * d, *Sdl = w.trans_dir_diff + (size_t)jlay * n * d;
+        or_real *El = w.trans_dir_dir + (size_t)jlay * d * d;
+        or_real *Idl = w.int_dir + (size_t)jlay * d * d, *Ifl = w.int_diff + (size_t)jlay * n * n;
+        or_real *Idfl = w.int_dir_diff + (size_t)jlay * n * d;
         int r0, nr; /* first region and number of regions in the sub-problem */
         if (!do_vegetation || veg_fraction[jlay] <= cfg->min_vegetation_fraction) {
           r0 = 0; nr = 1;
@@ -469,17 +469,17 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
       }
 
     for (int jlay = 0; jlay < nlay; ++jlay) {
-      const double *Rl = w.ref_diff + (size_t)jlay * n * n, *Tl = w.trans_diff + (size_t)jlay * n * n;
-      const double *Sul = w.ref_dir + (size_t)jlay * n * d, *Sdl = w.trans_dir_diff + (size_t)jlay * n * d;
-      const double *El = w.trans_dir_dir + (size_t)jlay * d * d;
-      const double *Aab = w.a_above + (size_t)jlay * n * n, *Dab = w.d_above + (size_t)jlay * n * d;
-      double *Den = w.denominator + (size_t)jlay * n * n;
-      double *Abe = w.a_below + (size_t)(jlay + 1) * nb * nb, *Dbe = w.d_below + (size_t)(jlay + 1) * nb * db;
-      double *Aab1 = w.a_above + (size_t)(jlay + 1) * n * n, *Dab1 = w.d_above + (size_t)(jlay + 1) * n * d;
-      const double *U = w.u_overlap + (size_t)(jlay + 1) * d * db;
-      const double *V = w.v_overlap + (size_t)(jlay + 1) * db * d;
-      double t1[OR_MAXN * OR_MAXN], t2[OR_MAXN * OR_MAXN], t3[OR_MAXN * OR_MAXN];
-      double r1[OR_MAXN * 3], r2[OR_MAXN * 3], r3[OR_MAXN * 3];
+      const or_real *Rl = w.ref_diff + (size_t)jlay * n * n, *Tl = w.trans_diff + (size_t)jlay * n * n;
+      const or_real *Sul = w.ref_dir + (size_t)jlay * n * d, *Sdl = w.trans_dir_diff + (size_t)jlay * n * d;
+      const or_real *El = w.trans_dir_dir + (size_t)jlay * d * d;
+      const or_real *Aab = w.a_above + (size_t)jlay * n * n, *Dab = w.d_above + (size_t)jlay * n * d;
+      or_real *Den = w.denominator + (size_t)jlay * n * n;
+      or_real *Abe = w.a_below + (size_t)(jlay + 1) * nb * nb, *Dbe = w.d_below + (size_t)(jlay + 1) * nb * db;
+      or_real *Aab1 = w.a_above + (size_t)(jlay + 1) * n * n, *Dab1 = w.d_above + (size_t)(jlay + 1) * n * d;
+      const or_real *U = w.u_overlap + (size_t)(jlay + 1) * d * db;
+      const or_real *V = w.v_overlap + (size_t)(jlay + 1) * db * d;
+      or_real t1[OR_MAXN * OR_MAXN], t2[OR_MAXN * OR_MAXN], t3[OR_MAXN * OR_MAXN];
+      or_real r1[OR_MAXN * 3], r2[OR_MAXN * 3], r3[OR_MAXN * 3];
 
       /* denominator = I - a_above*R  (identity_minus_mat_x_mat :655-690) */
       or_mat_x_mat(n, Aab, Rl, Den);
@@ -510,7 +510,7 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
       }
       /* overlap (:495-503 / :645-653) */
       {
-        double tA[OR_MAXN * OR_MAXN], tD[OR_MAXN * 3];
+        or_real tA[OR_MAXN * OR_MAXN], tD[OR_MAXN * 3];
         mat_x_expandedmat(db, d, ns, nb, Abe, V, tA);           /* nb x n  */
         expandedmat_x_mat(d, db, ns, n, U, tA, nb, Aab1);       /* n  x n  */
         /* rect_mat_x_singlemat :462-499: d_below (nb x db) * V (db x d) */
@@ -521,12 +521,12 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
 
     /* top-of-canopy boundary conditions (:520-528 / :666-674) */
     {
-      const double *At = w.a_above + (size_t)nlay * n * n;
-      const double *Dt = w.d_above + (size_t)nlay * n * d;
-      double y[MAXS], s = 0.0;
+      const or_real *At = w.a_above + (size_t)nlay * n * n;
+      const or_real *Dt = w.d_above + (size_t)nlay * n * d;
+      or_real y[MAXS], s = 0.0;
       /* mat_x_vec on the ns x ns top-left block, then sum over rows */
       for (int j1 = 0; j1 < ns; ++j1) {
-        double acc = 0.0;
+        or_real acc = 0.0;
         for (int j2 = 0; j2 < ns; ++j2) acc += E(At, j1, j2, n) * lg->hweight[j2];
         y[j1] = acc;
       }
@@ -542,10 +542,10 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
 #define FL(f, a, l) ((f)->a[jb + (size_t)nsw * (l0 + (l))])
     /* ===== fluxes normalized by the direct flux at canopy top (:538-676 / :686-859) ===== */
     {
-      double dir_above[4], dir_below[4], diff_above[OR_MAXN], diff_below[OR_MAXN];
-      double up_above[OR_MAXN], up_below[OR_MAXN], refl_dir[OR_MAXN];
-      double int_flux_dir[3], int_flux_diff[OR_MAXN], v1[OR_MAXN], v2[OR_MAXN], v3[OR_MAXN];
-      double flux_dn_dir_clear = 1.0 / cos_sza;
+      or_real dir_above[4], dir_below[4], diff_above[OR_MAXN], diff_below[OR_MAXN];
+      or_real up_above[OR_MAXN], up_below[OR_MAXN], refl_dir[OR_MAXN];
+      or_real int_flux_dir[3], int_flux_diff[OR_MAXN], v1[OR_MAXN], v2[OR_MAXN], v3[OR_MAXN];
+      or_real flux_dn_dir_clear = 1.0 / cos_sza;
       dir_above[0] = 1.0 / cos_sza;
       for (int r = 1; r < nreg; ++r) dir_above[r] = 0.0;
       for (int i = 0; i < n; ++i) { diff_above[i] = 0.0; up_above[i] = 0.0; }
@@ -555,18 +555,18 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
       if (is_urban && jb == 0 && fdir->roof_sunlit_frac) fdir->roof_sunlit_frac[l0 + nlay - 1] = 1.0;
 
       for (int jlay = nlay - 1; jlay >= 0; --jlay) {
-        const double *Rl = w.ref_diff + (size_t)jlay * n * n, *Tl = w.trans_diff + (size_t)jlay * n * n;
-        const double *Sdl = w.trans_dir_diff + (size_t)jlay * n * d;
-        const double *El = w.trans_dir_dir + (size_t)jlay * d * d;
-        const double *Idl = w.int_dir + (size_t)jlay * d * d, *Ifl = w.int_diff + (size_t)jlay * n * n;
-        const double *Idfl = w.int_dir_diff + (size_t)jlay * n * d;
-        const double *Aab = w.a_above + (size_t)jlay * n * n, *Dab = w.d_above + (size_t)jlay * n * d;
-        const double *Den = w.denominator + (size_t)jlay * n * n;
-        const double *Abe = w.a_below + (size_t)(jlay + 1) * nb * nb, *Dbe = w.d_below + (size_t)(jlay + 1) * nb * db;
-        const double *V = w.v_overlap + (size_t)(jlay + 1) * db * d;
-        const double *od = w.od_scaling + (size_t)jlay * (MAXREG + 1);
-        const double *f_wall = w.f_wall + (size_t)jlay * nreg;
-        const double air_ext = SPEC(sp->air_ext, jb, jlay), air_ssa = SPEC(sp->air_ssa, jb, jlay);
+        const or_real *Rl = w.ref_diff + (size_t)jlay * n * n, *Tl = w.trans_diff + (size_t)jlay * n * n;
+        const or_real *Sdl = w.trans_dir_diff + (size_t)jlay * n * d;
+        const or_real *El = w.trans_dir_dir + (size_t)jlay * d * d;
+        const or_real *Idl = w.int_dir + (size_t)jlay * d * d, *Ifl = w.int_diff + (size_t)jlay * n * n;
+        const or_real *Idfl = w.int_dir_diff + (size_t)jlay * n * d;
+        const or_real *Aab = w.a_above + (size_t)jlay * n * n, *Dab = w.d_above + (size_t)jlay * n * d;
+        const or_real *Den = w.denominator + (size_t)jlay * n * n;
+        const or_real *Abe = w.a_below + (size_t)(jlay + 1) * nb * nb, *Dbe = w.d_below + (size_t)(jlay + 1) * nb * db;
+        const or_real *V = w.v_overlap + (size_t)(jlay + 1) * db * d;
+        const or_real *od = w.od_scaling + (size_t)jlay * (MAXREG + 1);
+        const or_real *f_wall = w.f_wall + (size_t)jlay * nreg;
+        const or_real air_ext = SPEC(sp->air_ext, jb, jlay), air_ssa = SPEC(sp->air_ssa, jb, jlay);
 
         /* across the interface at the top of the layer */
         or_rect_mat_x_vec(db, d, V, db, dir_above, dir_below);   /* singlemat_x_vec / rect_singlemat_x_vec */
@@ -576,7 +576,7 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
         for (int i = 0; i < nb; ++i) up_below[i] = v1[i] + v2[i];
 
         if (is_urban) {
-          double s1 = 0.0, s2 = 0.0;
+          or_real s1 = 0.0, s2 = 0.0;
           FL(fdir, roof_in_dir, jlay) = cos_sza * dir_below[nreg];
           for (int i = n; i < nb; ++i) s1 += diff_below[i];
           FL(fdir, roof_in, jlay) = FL(fdir, roof_in_dir, jlay) + s1;
@@ -596,7 +596,7 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
         for (int i = 0; i < n; ++i) up_above[i] = v1[i] + refl_dir[i];
 
         if (fdir->flux_dn_layer_top) {
-          double s;
+          or_real s;
           s = 0.0; for (int r = 0; r < nreg; ++r) s += dir_below[r];
           FL(fdir, flux_dn_dir_layer_top, jlay) = cos_sza * s;
           s = 0.0; for (int i = 0; i < n; ++i) s += diff_below[i];
@@ -621,15 +621,15 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
 
         /* absorption (:608-628) */
         {
-          double s = 0.0;
+          or_real s = 0.0;
           for (int js = 0; js < ns; ++js) s += int_flux_diff[js] * (1.0 / lg->mu[js]);
           FL(fdir, clear_air_abs, jlay) = FL(fdir, clear_air_abs, jlay)
                                           + air_ext * (1.0 - air_ssa) * (int_flux_dir[0] + s);
         }
         if (do_vegetation) {
-          const double vssa = SPEC(sp->veg_ssa, jb, jlay);
+          const or_real vssa = SPEC(sp->veg_ssa, jb, jlay);
           for (int jreg = 1; jreg < nreg; ++jreg) {
-            double s = 0.0;
+            or_real s = 0.0;
             for (int js = 0; js < ns; ++js) s += int_flux_diff[jreg * ns + js] * (1.0 / lg->mu[js]);
             FL(fdir, veg_air_abs, jlay) = FL(fdir, veg_air_abs, jlay)
                                           + air_ext * (1.0 - air_ssa) * (int_flux_dir[jreg] + s);
@@ -646,7 +646,7 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
             FL(fdir, wall_in_dir, jlay) = FL(fdir, wall_in_dir, jlay) + f_wall[jreg] * sin0 * int_flux_dir[jreg];
           FL(fdir, wall_in, jlay) = FL(fdir, wall_in_dir, jlay);
           for (int jreg = 0; jreg < nreg; ++jreg) {
-            double s = 0.0;
+            or_real s = 0.0;
             for (int js = 0; js < ns; ++js) s += int_flux_diff[jreg * ns + js] * lg->tan_ang[js];
             FL(fdir, wall_in, jlay) = FL(fdir, wall_in, jlay) + f_wall[jreg] * s;
           }
@@ -655,31 +655,31 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
 
         /* sunlit fractions: only in the most transparent band */
         if (jb == itransp) {
-          const double ae = SPEC(sp->air_ext, itransp, jlay);
-          double trans_dir_clear, int_flux_dir_clear, veg_abs_dir_clear;
+          const or_real ae = SPEC(sp->air_ext, itransp, jlay);
+          or_real trans_dir_clear, int_flux_dir_clear, veg_abs_dir_clear;
           if (is_urban) {
             /* :804-812 */
             fdir->roof_sunlit_frac[l0 + jlay] = FL(fdir, roof_in_dir, jlay) * non_building_fraction[jlay + 1]
-                / (cos_sza * flux_dn_dir_clear * fmax(cfg->min_building_fraction, roof_fraction[jlay]));
+                / (cos_sza * flux_dn_dir_clear * OR_FMAX(cfg->min_building_fraction, roof_fraction[jlay]));
             flux_dn_dir_clear = flux_dn_dir_clear * non_building_fraction[jlay] / non_building_fraction[jlay + 1];
           }
-          trans_dir_clear = exp(-ae * dz[jlay] / cos_sza);
+          trans_dir_clear = OR_EXP(-ae * dz[jlay] / cos_sza);
           if (ae > 0.0) int_flux_dir_clear = flux_dn_dir_clear * (1.0 - trans_dir_clear) * cos_sza / ae;
           else int_flux_dir_clear = flux_dn_dir_clear * dz[jlay];
           if (do_vegetation) {
             veg_abs_dir_clear = int_flux_dir_clear * veg_ext[jlay]
                                 * (1.0 - SPEC(sp->veg_ssa, itransp, jlay)) * veg_fraction[jlay];
-            fdir->veg_sunlit_frac[l0 + jlay] = FL(fdir, veg_abs_dir, jlay) / fmax(DBL_EPSILON, veg_abs_dir_clear);
+            fdir->veg_sunlit_frac[l0 + jlay] = FL(fdir, veg_abs_dir, jlay) / OR_FMAX(DBL_EPSILON, veg_abs_dir_clear);
           }
           if (is_urban)
             fdir->wall_sunlit_frac[l0 + jlay] = 0.5 * FL(fdir, wall_in_dir, jlay)
-                / fmax(DBL_EPSILON, (w.f_wall_dir_clear[jlay] * sin0 * int_flux_dir_clear));
+                / OR_FMAX(DBL_EPSILON, (w.f_wall_dir_clear[jlay] * sin0 * int_flux_dir_clear));
           flux_dn_dir_clear = flux_dn_dir_clear * trans_dir_clear;
         }
       } /* layers downward */
 
       {
-        double s = 0.0, s2 = 0.0, s3 = 0.0;
+        or_real s = 0.0, s2 = 0.0, s3 = 0.0;
         for (int r = 0; r < nreg; ++r) s += dir_above[r];
         FC(fdir, ground_dn_dir) = cos_sza * s;
         for (int i = 0; i < n; ++i) s2 += diff_above[i];
@@ -699,8 +699,8 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
 
     /* ===== fluxes normalized by the diffuse flux at canopy top (:678-760 / :876-984) ===== */
     {
-      double diff_above[OR_MAXN], diff_below[OR_MAXN], up_above[OR_MAXN], up_below[OR_MAXN];
-      double int_flux_diff[OR_MAXN], v1[OR_MAXN], v2[OR_MAXN];
+      or_real diff_above[OR_MAXN], diff_below[OR_MAXN], up_above[OR_MAXN], up_below[OR_MAXN];
+      or_real int_flux_diff[OR_MAXN], v1[OR_MAXN], v2[OR_MAXN];
       for (int i = 0; i < n; ++i) { diff_above[i] = 0.0; up_above[i] = 0.0; }
       for (int js = 0; js < ns; ++js) diff_above[js] = lg->hweight[js];
       FC(fdiff, top_dn_dir) = 0.0;
@@ -708,20 +708,20 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
       FC(fdiff, top_net) = 1.0 - top_albedo_diff[jb];
 
       for (int jlay = nlay - 1; jlay >= 0; --jlay) {
-        const double *Tl = w.trans_diff + (size_t)jlay * n * n;
-        const double *Ifl = w.int_diff + (size_t)jlay * n * n;
-        const double *Aab = w.a_above + (size_t)jlay * n * n;
-        const double *Den = w.denominator + (size_t)jlay * n * n;
-        const double *Abe = w.a_below + (size_t)(jlay + 1) * nb * nb;
-        const double *V = w.v_overlap + (size_t)(jlay + 1) * db * d;
-        const double *od = w.od_scaling + (size_t)jlay * (MAXREG + 1);
-        const double *f_wall = w.f_wall + (size_t)jlay * nreg;
-        const double air_ext = SPEC(sp->air_ext, jb, jlay), air_ssa = SPEC(sp->air_ssa, jb, jlay);
+        const or_real *Tl = w.trans_diff + (size_t)jlay * n * n;
+        const or_real *Ifl = w.int_diff + (size_t)jlay * n * n;
+        const or_real *Aab = w.a_above + (size_t)jlay * n * n;
+        const or_real *Den = w.denominator + (size_t)jlay * n * n;
+        const or_real *Abe = w.a_below + (size_t)(jlay + 1) * nb * nb;
+        const or_real *V = w.v_overlap + (size_t)(jlay + 1) * db * d;
+        const or_real *od = w.od_scaling + (size_t)jlay * (MAXREG + 1);
+        const or_real *f_wall = w.f_wall + (size_t)jlay * nreg;
+        const or_real air_ext = SPEC(sp->air_ext, jb, jlay), air_ssa = SPEC(sp->air_ssa, jb, jlay);
 
         expandedmat_x_vec(db, d, ns, V, diff_above, diff_below);
         or_mat_x_vec(nb, Abe, diff_below, up_below);
         if (is_urban) {
-          double s1 = 0.0, s2 = 0.0;
+          or_real s1 = 0.0, s2 = 0.0;
           for (int i = n; i < nb; ++i) s1 += diff_below[i];
           FL(fdiff, roof_in, jlay) = +s1;
           for (int i = n; i < nb; ++i) s2 += up_below[i];
@@ -732,7 +732,7 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
         or_mat_x_vec(n, Aab, diff_above, up_above);
 
         if (fdiff->flux_dn_layer_top) {
-          double s;
+          or_real s;
           s = 0.0; for (int i = 0; i < n; ++i) s += diff_below[i];
           FL(fdiff, flux_dn_layer_top, jlay) = s;
           s = 0.0; for (int i = 0; i < n; ++i) s += up_below[i];
@@ -747,14 +747,14 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
         or_mat_x_vec(n, Ifl, v2, int_flux_diff);
 
         {
-          double s = 0.0;
+          or_real s = 0.0;
           for (int js = 0; js < ns; ++js) s += int_flux_diff[js] * (1.0 / lg->mu[js]);
           FL(fdiff, clear_air_abs, jlay) = FL(fdiff, clear_air_abs, jlay) + air_ext * (1.0 - air_ssa) * s;
         }
         if (do_vegetation) {
-          const double vssa = SPEC(sp->veg_ssa, jb, jlay);
+          const or_real vssa = SPEC(sp->veg_ssa, jb, jlay);
           for (int jreg = 1; jreg < nreg; ++jreg) {
-            double s = 0.0;
+            or_real s = 0.0;
             for (int js = 0; js < ns; ++js) s += int_flux_diff[jreg * ns + js] * (1.0 / lg->mu[js]);
             FL(fdiff, veg_air_abs, jlay) = FL(fdiff, veg_air_abs, jlay) + air_ext * (1.0 - air_ssa) * s;
             FL(fdiff, veg_abs, jlay) = FL(fdiff, veg_abs, jlay) + veg_ext[jlay] * (1.0 - vssa) * s * od[jreg];
@@ -762,7 +762,7 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
         }
         if (is_urban) {
           for (int jreg = 0; jreg < nreg; ++jreg) {
-            double s = 0.0;
+            or_real s = 0.0;
             for (int js = 0; js < ns; ++js) s += int_flux_diff[jreg * ns + js] * lg->tan_ang[js];
             FL(fdiff, wall_in, jlay) = FL(fdiff, wall_in, jlay) + f_wall[jreg] * (s);
           }
@@ -770,7 +770,7 @@ static int solve_sw(const ss_config *cfg, int is_urban, int nsw, int ns, int nre
         }
       }
       {
-        double s2 = 0.0, s3 = 0.0;
+        or_real s2 = 0.0, s3 = 0.0;
         FC(fdiff, ground_dn_dir) = 0.0;
         for (int i = 0; i < n; ++i) s2 += diff_above[i];
         FC(fdiff, ground_dn) = s2;
@@ -840,44 +840,44 @@ static int solve_lw(const ss_config *cfg, int is_urban, int nlw, int ns, int nre
   flux_zero(fnorm, icol, l0, nlay);
 
   for (int jb = 0; jb < nlw; ++jb) {
-    double gamma1[OR_MAXN * OR_MAXN], gamma2[OR_MAXN * OR_MAXN], emiss_rate[OR_MAXN];
-    double f_exchange[9], ext_reg[3], ssa_reg[3], planck_reg[3];
-    double sub1[OR_MAXN * OR_MAXN], sub2[OR_MAXN * OR_MAXN];
-    double oR[OR_MAXN * OR_MAXN], oT[OR_MAXN * OR_MAXN], oS[OR_MAXN], oIf[OR_MAXN * OR_MAXN], oIs[OR_MAXN];
-    double emiss_factor;
-    const double ground_emissivity = sp->ground_emissivity[jb + (size_t)nlw * icol];
-    const double ground_emission = sp->ground_emission[jb + (size_t)nlw * icol];
+    or_real gamma1[OR_MAXN * OR_MAXN], gamma2[OR_MAXN * OR_MAXN], emiss_rate[OR_MAXN];
+    or_real f_exchange[9], ext_reg[3], ssa_reg[3], planck_reg[3];
+    or_real sub1[OR_MAXN * OR_MAXN], sub2[OR_MAXN * OR_MAXN];
+    or_real oR[OR_MAXN * OR_MAXN], oT[OR_MAXN * OR_MAXN], oS[OR_MAXN], oIf[OR_MAXN * OR_MAXN], oIs[OR_MAXN];
+    or_real emiss_factor;
+    const or_real ground_emissivity = sp->ground_emissivity[jb + (size_t)nlw * icol];
+    const or_real ground_emission = sp->ground_emission[jb + (size_t)nlw * icol];
 
     for (int jlay = 0; jlay < nlay; ++jlay) {
-      const double *frac = w.frac + (size_t)jlay * nreg;
-      const double *norm_perim = w.norm_perim + (size_t)jlay * nreg;
-      double *od = w.od_scaling + (size_t)jlay * (MAXREG + 1);
-      double *f_wall = w.f_wall + (size_t)jlay * nreg;
-      double wall_ext = 1.0, wall_factor = 0.0;
-      const double air_ext = SPEC(sp->air_ext, jb, jlay), air_ssa = SPEC(sp->air_ssa, jb, jlay);
-      const double vext = do_vegetation ? veg_ext[jlay] : 0.0;
-      const double vssa = do_vegetation ? SPEC(sp->veg_ssa, jb, jlay) : 0.0;
-      const double vplanck = do_vegetation ? SPEC(sp->veg_planck, jb, jlay) : 0.0;
-      const double vaplanck = do_vegetation ? SPEC(sp->veg_air_planck, jb, jlay) : 0.0;
+      const or_real *frac = w.frac + (size_t)jlay * nreg;
+      const or_real *norm_perim = w.norm_perim + (size_t)jlay * nreg;
+      or_real *od = w.od_scaling + (size_t)jlay * (MAXREG + 1);
+      or_real *f_wall = w.f_wall + (size_t)jlay * nreg;
+      or_real wall_ext = 1.0, wall_factor = 0.0;
+      const or_real air_ext = SPEC(sp->air_ext, jb, jlay), air_ssa = SPEC(sp->air_ssa, jb, jlay);
+      const or_real vext = do_vegetation ? veg_ext[jlay] : 0.0;
+      const or_real vssa = do_vegetation ? SPEC(sp->veg_ssa, jb, jlay) : 0.0;
+      const or_real vplanck = do_vegetation ? SPEC(sp->veg_planck, jb, jlay) : 0.0;
+      const or_real vaplanck = do_vegetation ? SPEC(sp->veg_air_planck, jb, jlay) : 0.0;
 
       region_optics(nreg, air_ext, air_ssa, vext, vssa, (nreg == 3) ? veg_fsd[jlay] : 0.0,
                     od, ext_reg, ssa_reg);
       planck_reg[0] = SPEC(sp->clear_air_planck, jb, jlay);
       if (nreg == 2) {
         planck_reg[1] = (ext_reg[0] * (1.0 - ssa_reg[0]) * vaplanck + vext * (1.0 - vssa) * vplanck)
-                        / fmax(ext_reg[1] * (1.0 - ssa_reg[1]), 1.0e-8);
+                        / OR_FMAX(ext_reg[1] * (1.0 - ssa_reg[1]), 1.0e-8);
       } else if (nreg == 3) {
         planck_reg[1] = (ext_reg[0] * (1.0 - ssa_reg[0]) * vaplanck + od[1] * vext * (1.0 - vssa) * vplanck)
-                        / fmax(ext_reg[1] * (1.0 - ssa_reg[1]), 1.0e-8);
+                        / OR_FMAX(ext_reg[1] * (1.0 - ssa_reg[1]), 1.0e-8);
         planck_reg[2] = (ext_reg[0] * (1.0 - ssa_reg[0]) * vaplanck + od[2] * vext * (1.0 - vssa) * vplanck)
-                        / fmax(ext_reg[2] * (1.0 - ssa_reg[2]), 1.0e-8);
+                        / OR_FMAX(ext_reg[2] * (1.0 - ssa_reg[2]), 1.0e-8);
       }
       exchange_rates(nreg, frac, norm_perim, cfg->min_vegetation_fraction, f_exchange);
 
       for (int r = 0; r < nreg; ++r) f_wall[r] = 0.0;
       if (is_urban) {
         /* radsurf_urban_lw.F90:372-392; wall_factor uses band 1 (Appendix B item 3) */
-        const double *npw = w.norm_perim_wall + (size_t)jlay * nreg;
+        const or_real *npw = w.norm_perim_wall + (size_t)jlay * nreg;
         for (int r = 0; r < nreg; ++r) {
           if (frac[r] <= cfg->min_vegetation_fraction) f_wall[r] = 0.0;
           else f_wall[r] = npw[r] * lg->vadjustment2 / (Pi * frac[r]);
@@ -921,8 +921,8 @@ static int solve_lw(const ss_config *cfg, int is_urban, int nlw, int ns, int nre
       for (int js = 0; js < ns; ++js) emiss_factor += lg->hweight[js] / lg->mu[js];
       emiss_factor = 2.0 * emiss_factor;
       for (int jreg = 0; jreg < nreg; ++jreg) {
-        const double volume_emiss = frac[jreg] * (ext_reg[jreg] * (1.0 - ssa_reg[jreg]) * planck_reg[jreg]);
-        double wall_emiss = 0.0;
+        const or_real volume_emiss = frac[jreg] * (ext_reg[jreg] * (1.0 - ssa_reg[jreg]) * planck_reg[jreg]);
+        or_real wall_emiss = 0.0;
         if (is_urban)
           wall_emiss = w.norm_perim_wall[(size_t)jlay * nreg + jreg] * lg->vadjustment
                        * SPEC(sp->wall_emission, jb, jlay);
@@ -942,16 +942,16 @@ static int solve_lw(const ss_config *cfg, int is_urban, int nlw, int ns, int nre
         }
       }
       if (is_urban) {
-        double s = 0.0;
+        or_real s = 0.0;
         for (int r = 0; r < nreg; ++r) s += w.norm_perim_wall[(size_t)jlay * nreg + r];
         w.emiss_wall[jlay] = (s * lg->vadjustment) * SPEC(sp->wall_emission, jb, jlay);
       }
 
       /* layer matrices, 3-way branch */
       {
-        double *Rl = w.ref_diff + (size_t)jlay * n * n, *Tl = w.trans_diff + (size_t)jlay * n * n;
-        double *Sl = w.source_lay + (size_t)jlay * n, *Ifl = w.int_diff + (size_t)jlay * n * n;
-        double *Isl = w.int_source + (size_t)jlay * n;
+        or_real *Rl = w.ref_diff + (size_t)jlay * n * n, *Tl = w.trans_diff + (size_t)jlay * n * n;
+        or_real *Sl = w.source_lay + (size_t)jlay * n, *Ifl = w.int_diff + (size_t)jlay * n * n;
+        or_real *Isl = w.int_source + (size_t)jlay * n;
         int r0, nr;
         if (!do_vegetation || veg_fraction[jlay] <= cfg->min_vegetation_fraction) {
           r0 = 0; nr = 1;
@@ -988,16 +988,16 @@ static int solve_lw(const ss_config *cfg, int is_urban, int nlw, int ns, int nre
         w.source_above[js + jreg * ns] = (lg->hweight[js] * w.frac[jreg]) * ground_emission;
     }
     for (int jlay = 0; jlay < nlay; ++jlay) {
-      const double *Rl = w.ref_diff + (size_t)jlay * n * n, *Tl = w.trans_diff + (size_t)jlay * n * n;
-      const double *Sl = w.source_lay + (size_t)jlay * n;
-      const double *Aab = w.a_above + (size_t)jlay * n * n, *Sab = w.source_above + (size_t)jlay * n;
-      double *Den = w.denominator + (size_t)jlay * n * n;
-      double *Abe = w.a_below + (size_t)(jlay + 1) * nb * nb, *Sbe = w.source_below + (size_t)(jlay + 1) * nb;
-      double *Aab1 = w.a_above + (size_t)(jlay + 1) * n * n, *Sab1 = w.source_above + (size_t)(jlay + 1) * n;
-      const double *U = w.u_overlap + (size_t)(jlay + 1) * d * db;
-      const double *V = w.v_overlap + (size_t)(jlay + 1) * db * d;
-      double t1[OR_MAXN * OR_MAXN], t2[OR_MAXN * OR_MAXN], t3[OR_MAXN * OR_MAXN];
-      double v1[OR_MAXN], v2[OR_MAXN];
+      const or_real *Rl = w.ref_diff + (size_t)jlay * n * n, *Tl = w.trans_diff + (size_t)jlay * n * n;
+      const or_real *Sl = w.source_lay + (size_t)jlay * n;
+      const or_real *Aab = w.a_above + (size_t)jlay * n * n, *Sab = w.source_above + (size_t)jlay * n;
+      or_real *Den = w.denominator + (size_t)jlay * n * n;
+      or_real *Abe = w.a_below + (size_t)(jlay + 1) * nb * nb, *Sbe = w.source_below + (size_t)(jlay + 1) * nb;
+      or_real *Aab1 = w.a_above + (size_t)(jlay + 1) * n * n, *Sab1 = w.source_above + (size_t)(jlay + 1) * n;
+      const or_real *U = w.u_overlap + (size_t)(jlay + 1) * d * db;
+      const or_real *V = w.v_overlap + (size_t)(jlay + 1) * db * d;
+      or_real t1[OR_MAXN * OR_MAXN], t2[OR_MAXN * OR_MAXN], t3[OR_MAXN * OR_MAXN];
+      or_real v1[OR_MAXN], v2[OR_MAXN];
 
       or_mat_x_mat(n, Aab, Rl, Den);
       for (int k = 0; k < n * n; ++k) Den[k] = -Den[k];
@@ -1014,8 +1014,8 @@ static int solve_lw(const ss_config *cfg, int is_urban, int nlw, int ns, int nre
       or_mat_x_vec(n, Tl, v2, v1);
       for (int i = 0; i < n; ++i) Sbe[i] = Sl[i] + v1[i];
       if (is_urban) {
-        double exposed_roof_frac;
-        if (jlay < nlay - 1) exposed_roof_frac = fmax(0.0, building_fraction[jlay] - building_fraction[jlay + 1]);
+        or_real exposed_roof_frac;
+        if (jlay < nlay - 1) exposed_roof_frac = OR_FMAX(0.0, building_fraction[jlay] - building_fraction[jlay + 1]);
         else exposed_roof_frac = building_fraction[jlay];
         for (int js = 0; js < ns; ++js) {
           for (int js2 = 0; js2 < ns; ++js2)
@@ -1024,18 +1024,18 @@ static int solve_lw(const ss_config *cfg, int is_urban, int nlw, int ns, int nre
         }
       }
       {
-        double tA[OR_MAXN * OR_MAXN];
+        or_real tA[OR_MAXN * OR_MAXN];
         mat_x_expandedmat(db, d, ns, nb, Abe, V, tA);
         expandedmat_x_mat(d, db, ns, n, U, tA, nb, Aab1);
         expandedmat_x_vec(d, db, ns, U, Sbe, Sab1);
       }
     }
     {
-      const double *At = w.a_above + (size_t)nlay * n * n;
-      const double *St = w.source_above + (size_t)nlay * n;
-      double y[MAXS], s = 0.0;
+      const or_real *At = w.a_above + (size_t)nlay * n * n;
+      const or_real *St = w.source_above + (size_t)nlay * n;
+      or_real y[MAXS], s = 0.0;
       for (int j1 = 0; j1 < ns; ++j1) {
-        double acc = 0.0;
+        or_real acc = 0.0;
         for (int j2 = 0; j2 < ns; ++j2) acc += E(At, j1, j2, n) * lg->hweight[j2];
         y[j1] = acc;
       }
@@ -1049,8 +1049,8 @@ static int solve_lw(const ss_config *cfg, int is_urban, int nlw, int ns, int nre
     /* Section 5: two downward passes: kind 0 = internal emission, 1 = incoming */
     for (int kind = 0; kind < 2; ++kind) {
       ss_flux *f = kind == 0 ? fint : fnorm;
-      double dn_above[OR_MAXN], dn_below[OR_MAXN], up_above[OR_MAXN], up_below[OR_MAXN];
-      double int_flux[OR_MAXN], v1[OR_MAXN], v2[OR_MAXN];
+      or_real dn_above[OR_MAXN], dn_below[OR_MAXN], up_above[OR_MAXN], up_below[OR_MAXN];
+      or_real int_flux[OR_MAXN], v1[OR_MAXN], v2[OR_MAXN];
       for (int i = 0; i < n; ++i) { dn_above[i] = 0.0; up_above[i] = 0.0; }
       if (kind == 0) {
         FC(f, top_dn) = 0.0;
@@ -1061,22 +1061,22 @@ static int solve_lw(const ss_config *cfg, int is_urban, int nlw, int ns, int nre
         FC(f, top_net) = top_emissivity[jb];
       }
       for (int jlay = nlay - 1; jlay >= 0; --jlay) {
-        const double *Rl = w.ref_diff + (size_t)jlay * n * n, *Tl = w.trans_diff + (size_t)jlay * n * n;
-        const double *Sl = w.source_lay + (size_t)jlay * n, *Ifl = w.int_diff + (size_t)jlay * n * n;
-        const double *Isl = w.int_source + (size_t)jlay * n;
-        const double *Aab = w.a_above + (size_t)jlay * n * n, *Sab = w.source_above + (size_t)jlay * n;
-        const double *Den = w.denominator + (size_t)jlay * n * n;
-        const double *Abe = w.a_below + (size_t)(jlay + 1) * nb * nb, *Sbe = w.source_below + (size_t)(jlay + 1) * nb;
-        const double *V = w.v_overlap + (size_t)(jlay + 1) * db * d;
-        const double *od = w.od_scaling + (size_t)jlay * (MAXREG + 1);
-        const double *f_wall = w.f_wall + (size_t)jlay * nreg;
-        const double air_ext = SPEC(sp->air_ext, jb, jlay), air_ssa = SPEC(sp->air_ssa, jb, jlay);
+        const or_real *Rl = w.ref_diff + (size_t)jlay * n * n, *Tl = w.trans_diff + (size_t)jlay * n * n;
+        const or_real *Sl = w.source_lay + (size_t)jlay * n, *Ifl = w.int_diff + (size_t)jlay * n * n;
+        const or_real *Isl = w.int_source + (size_t)jlay * n;
+        const or_real *Aab = w.a_above + (size_t)jlay * n * n, *Sab = w.source_above + (size_t)jlay * n;
+        const or_real *Den = w.denominator + (size_t)jlay * n * n;
+        const or_real *Abe = w.a_below + (size_t)(jlay + 1) * nb * nb, *Sbe = w.source_below + (size_t)(jlay + 1) * nb;
+        const or_real *V = w.v_overlap + (size_t)(jlay + 1) * db * d;
+        const or_real *od = w.od_scaling + (size_t)jlay * (MAXREG + 1);
+        const or_real *f_wall = w.f_wall + (size_t)jlay * nreg;
+        const or_real air_ext = SPEC(sp->air_ext, jb, jlay), air_ssa = SPEC(sp->air_ssa, jb, jlay);
 
         expandedmat_x_vec(db, d, ns, V, dn_above, dn_below);
         or_mat_x_vec(nb, Abe, dn_below, up_below);
         if (kind == 0) for (int i = 0; i < nb; ++i) up_below[i] = up_below[i] + Sbe[i];
         if (is_urban) {
-          double s1 = 0.0, s2 = 0.0;
+          or_real s1 = 0.0, s2 = 0.0;
           for (int i = n; i < nb; ++i) s1 += dn_below[i];
           FL(f, roof_in, jlay) = s1;
           for (int i = n; i < nb; ++i) s2 += up_below[i];
@@ -1092,7 +1092,7 @@ static int solve_lw(const ss_config *cfg, int is_urban, int nlw, int ns, int nre
         if (kind == 0) for (int i = 0; i < n; ++i) up_above[i] = up_above[i] + Sab[i];
 
         if (f->flux_dn_layer_top) {
-          double s;
+          or_real s;
           s = 0.0; for (int i = 0; i < n; ++i) s += dn_below[i];
           FL(f, flux_dn_layer_top, jlay) = s;
           s = 0.0; for (int i = 0; i < n; ++i) s += up_below[i];
@@ -1108,7 +1108,7 @@ static int solve_lw(const ss_config *cfg, int is_urban, int nlw, int ns, int nre
         if (kind == 0) for (int i = 0; i < n; ++i) int_flux[i] = int_flux[i] + Isl[i];
 
         {
-          double s = 0.0;
+          or_real s = 0.0;
           for (int js = 0; js < ns; ++js) s += int_flux[js] * (1.0 / lg->mu[js]);
           if (kind == 0)
             FL(f, clear_air_abs, jlay) = FL(f, clear_air_abs, jlay) + air_ext * (1.0 - air_ssa) * s
@@ -1117,9 +1117,9 @@ static int solve_lw(const ss_config *cfg, int is_urban, int nlw, int ns, int nre
             FL(f, clear_air_abs, jlay) = FL(f, clear_air_abs, jlay) + air_ext * (1.0 - air_ssa) * s;
         }
         if (do_vegetation) {
-          const double vssa = SPEC(sp->veg_ssa, jb, jlay);
+          const or_real vssa = SPEC(sp->veg_ssa, jb, jlay);
           for (int jreg = 1; jreg < nreg; ++jreg) {
-            double s = 0.0;
+            or_real s = 0.0;
             for (int js = 0; js < ns; ++js) s += int_flux[jreg * ns + js] * (1.0 / lg->mu[js]);
             if (kind == 0) {
               FL(f, veg_air_abs, jlay) = FL(f, veg_air_abs, jlay) + air_ext * (1.0 - air_ssa) * s
@@ -1134,7 +1134,7 @@ static int solve_lw(const ss_config *cfg, int is_urban, int nlw, int ns, int nre
         }
         if (is_urban) {
           for (int jreg = 0; jreg < nreg; ++jreg) {
-            double s = 0.0;
+            or_real s = 0.0;
             for (int js = 0; js < ns; ++js) s += int_flux[jreg * ns + js] * lg->tan_ang[js];
             FL(f, wall_in, jlay) = FL(f, wall_in, jlay) + f_wall[jreg] * s;
           }
@@ -1146,7 +1146,7 @@ static int solve_lw(const ss_config *cfg, int is_urban, int nlw, int ns, int nre
         }
       }
       {
-        double s2 = 0.0, s3 = 0.0;
+        or_real s2 = 0.0, s3 = 0.0;
         /* forest LW accumulates BOTH passes into lw_internal%ground_vertical_diff
          * (radsurf_forest_lw.F90:691); urban uses lw_norm */
         ss_flux *fv = (kind == 1 && !is_urban) ? fint : f;
@@ -1179,11 +1179,11 @@ static int simple_spectrum_lw(const ss_config *cfg, const ss_canopy *cp, const s
   int ilay2 = cp->istartlay[iendcol - 1] + cp->nlay[iendcol - 1] - 1;
   if (lw->nspec > 1) return SS_ERR_BAD_ARGUMENT;
   for (int c = istartcol - 1; c < iendcol; ++c) {
-    double t = cp->ground_temperature[c];
+    or_real t = cp->ground_temperature[c];
     lw->ground_emission[c] = StefanBoltzmann * lw->ground_emissivity[c] * (t * t * t * t);
   }
   for (int l = ilay1 - 1; l < ilay2; ++l) {
-    double t;
+    or_real t;
     if (lw->roof_emission) {
       t = cp->roof_temperature[l];
       lw->roof_emission[l] = StefanBoltzmann * lw->roof_emissivity[l] * (t * t * t * t);
@@ -1331,18 +1331,18 @@ int spartacus_radsurf_oracle(const ss_config *config, const ss_canopy *canopy,
 
 /* ---- kernel-level entries on (nmat, i, j) stacked Fortran-layout arrays ---- */
 
-static void unstack(const double *src, int nmat, int jmat, int rows, int cols, double *dst) {
+static void unstack(const double *src, int nmat, int jmat, int rows, int cols, or_real *dst) {
   for (int j = 0; j < cols; ++j)
     for (int i = 0; i < rows; ++i) dst[i + (size_t)j * rows] = src[jmat + (size_t)nmat * (i + (size_t)rows * j)];
 }
-static void restack(const double *src, int nmat, int jmat, int rows, int cols, double *dst) {
+static void restack(const or_real *src, int nmat, int jmat, int rows, int cols, double *dst) {
   for (int j = 0; j < cols; ++j)
     for (int i = 0; i < rows; ++i) dst[jmat + (size_t)nmat * (i + (size_t)rows * j)] = src[i + (size_t)j * rows];
 }
 
 void oracle_eigen_decomposition_real(int32_t norder, int32_t nmat, const double *amat,
                                      double *eigenvalue, double *eigenvector) {
-  double a[OR_MAXN * OR_MAXN], val[OR_MAXN], vec[OR_MAXN * OR_MAXN];
+  or_real a[OR_MAXN * OR_MAXN], val[OR_MAXN], vec[OR_MAXN * OR_MAXN];
   for (int m = 0; m < nmat; ++m) {
     unstack(amat, nmat, m, norder, norder, a);
     memset(vec, 0, sizeof(vec));
@@ -1357,9 +1357,9 @@ void oracle_calc_matrices_sw_eig(int32_t nmat, int32_t ndiff, int32_t ndir, doub
                                  const double *gamma3, double *reflectance, double *transmittance,
                                  double *s_up, double *s_dn, double *trans_dir, double *int_dir,
                                  double *int_diff, double *int_dir_diff) {
-  double g0[9], g1[OR_MAXN * OR_MAXN], g2[OR_MAXN * OR_MAXN], g3[OR_MAXN * 3];
-  double oR[OR_MAXN * OR_MAXN], oT[OR_MAXN * OR_MAXN], oSu[OR_MAXN * 3], oSd[OR_MAXN * 3];
-  double oE[9], oId[9], oIf[OR_MAXN * OR_MAXN], oIdf[OR_MAXN * 3];
+  or_real g0[9], g1[OR_MAXN * OR_MAXN], g2[OR_MAXN * OR_MAXN], g3[OR_MAXN * 3];
+  or_real oR[OR_MAXN * OR_MAXN], oT[OR_MAXN * OR_MAXN], oSu[OR_MAXN * 3], oSd[OR_MAXN * 3];
+  or_real oE[9], oId[9], oIf[OR_MAXN * OR_MAXN], oIdf[OR_MAXN * 3];
   for (int m = 0; m < nmat; ++m) {
     unstack(gamma0, nmat, m, ndir, ndir, g0);
     unstack(gamma1, nmat, m, ndiff, ndiff, g1);
@@ -1381,8 +1381,8 @@ void oracle_calc_matrices_lw_eig(int32_t nmat, int32_t norder, double dz, const 
                                  const double *gamma2, const double *emiss_rate, double *reflectance,
                                  double *transmittance, double *source, double *int_flux,
                                  double *int_flux_source) {
-  double g1[OR_MAXN * OR_MAXN], g2[OR_MAXN * OR_MAXN], b[OR_MAXN];
-  double oR[OR_MAXN * OR_MAXN], oT[OR_MAXN * OR_MAXN], oS[OR_MAXN], oIf[OR_MAXN * OR_MAXN], oIs[OR_MAXN];
+  or_real g1[OR_MAXN * OR_MAXN], g2[OR_MAXN * OR_MAXN], b[OR_MAXN];
+  or_real oR[OR_MAXN * OR_MAXN], oT[OR_MAXN * OR_MAXN], oS[OR_MAXN], oIf[OR_MAXN * OR_MAXN], oIs[OR_MAXN];
   for (int m = 0; m < nmat; ++m) {
     unstack(gamma1, nmat, m, norder, norder, g1);
     unstack(gamma2, nmat, m, norder, norder, g2);

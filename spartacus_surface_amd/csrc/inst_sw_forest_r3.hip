@@ -1,0 +1,6 @@
+// Instantiation unit: sw solver kernels, forest tiles, 3 region(s), ns = 1, 2, 4, 8
+#define SS_INST_URBAN false
+#define SS_INST_NREG 3
+#define SS_INST_LW 0
+#define SS_INST_NAME launch_sw_forest_r3
+#include "ss_inst_body.hpp"

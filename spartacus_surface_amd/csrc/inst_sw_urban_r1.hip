@@ -1,0 +1,6 @@
+// Instantiation unit: sw solver kernels, urban tiles, 1 region(s), ns = 1, 2, 4, 8
+#define SS_INST_URBAN true
+#define SS_INST_NREG 1
+#define SS_INST_LW 0
+#define SS_INST_NAME launch_sw_urban_r1
+#include "ss_inst_body.hpp"

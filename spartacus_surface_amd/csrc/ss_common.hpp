@@ -1,0 +1,142 @@
+// ss_common.hpp - shared definitions of the gfx950 SPARTACUS-Surface kernels.
+//
+// Execution model: one wavefront lane owns one independent
+// problem for its whole lifetime - a (column, band, layer) unit in the layer
+// kernels, a (column, band) unit in the column kernels.  All small dense
+// algebra of a unit lives in that lane's registers (compile-time matrix orders,
+// fully unrolled for n <= 6); units exchange data only through HBM scratch laid
+// out [layer][element][unit] so that the 64 lanes of a wave always touch 64
+// consecutive doubles (512 B, coalesced).
+//
+// The per-unit bodies are __host__ __device__ so that a TEST-ONLY host build
+// (tests/emul) can run them under sanitizers / gdb; the product library only
+// ever launches them as HIP kernels.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cfloat>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SS_HD __host__ __device__ __forceinline__
+#define SS_HD_NOINLINE __host__ __device__ __noinline__
+#else
+#define SS_HD inline
+#define SS_HD_NOINLINE
+#endif
+
+// Loop unrolling policy: orders up to SS_UNROLL_MAX are fully unrolled so that
+// every matrix element has a compile-time register; larger orders keep rolled
+// loops (arrays then live in scratch memory).
+#define SS_UNROLL_MAX 6
+#define SS_PRAGMA(x) _Pragma(#x)
+#define SS_UNROLL_N(N) SS_PRAGMA(unroll((N) <= SS_UNROLL_MAX ? (N) : 1))
+#define SS_UNROLL_NN(N) SS_PRAGMA(unroll((N) <= SS_UNROLL_MAX ? (N) * (N) : 1))
+#define SS_UNROLL_FULL SS_PRAGMA(unroll)
+
+namespace ss {
+
+constexpr double kPi = 3.14159265358979323846;   // radtool/radiation_constants.F90:24
+constexpr double kStefanBoltzmann = 5.67037321e-8;  // radiation_constants.F90:26
+constexpr int kDevMaxStreams = 8;                // instantiated stream counts: 1,2,4,8
+
+// Legendre-Gauss table as kernel constant (radtool_legendre_gauss.F90:25-48)
+struct LG {
+  double mu[kDevMaxStreams];
+  double tan_ang[kDevMaxStreams];
+  double weight[kDevMaxStreams];
+  double hweight[kDevMaxStreams];
+  double vweight[kDevMaxStreams];
+  double vadjustment;
+  double vadjustment2;
+};
+
+// Scalars of config_type the solvers read (radsurf_config.F90:32-113)
+struct Cfg {
+  double min_vegetation_fraction;
+  double min_building_fraction;
+  double vegetation_isolation_factor;   // of the tile kind (forest / urban)
+  int use_symmetric_vegetation_scale;   // of the tile kind
+  int do_vegetation;
+};
+
+// canopy_flux_type members by index (order of radsurf_canopy_flux.F90:27-91,
+// = order of ss_flux in the C-ABI header)
+enum FluxField {
+  F_GROUND_DN = 0, F_GROUND_DN_DIR, F_GROUND_NET, F_TOP_DN, F_TOP_DN_DIR, F_TOP_NET,
+  F_ROOF_IN, F_ROOF_IN_DIR, F_ROOF_NET, F_WALL_IN, F_WALL_IN_DIR, F_WALL_NET,
+  F_ROOF_SUNLIT_FRAC, F_WALL_SUNLIT_FRAC, F_GROUND_SUNLIT_FRAC, F_GROUND_VERTICAL_DIFF,
+  F_CLEAR_AIR_ABS, F_VEG_ABS, F_VEG_AIR_ABS, F_VEG_ABS_DIR, F_VEG_SUNLIT_FRAC,
+  F_FLUX_DN_LAYER_TOP, F_FLUX_DN_DIR_LAYER_TOP, F_FLUX_UP_LAYER_TOP,
+  F_FLUX_DN_LAYER_BASE, F_FLUX_DN_DIR_LAYER_BASE, F_FLUX_UP_LAYER_BASE,
+  F_NFIELDS
+};
+
+struct FluxDev {
+  double* f[F_NFIELDS];   // nullptr = member not allocated
+};
+
+// Device mirrors of the input arrays, same layout as the host (Fortran) arrays
+struct Inputs {
+  const int32_t* nlay;        // (ncol)
+  const int32_t* istartlay;   // (ncol) 1-based
+  const double* cos_sza;      // (ncol)
+  const double* dz;
+  const double* building_fraction;
+  const double* veg_fraction;
+  const double* building_scale;
+  const double* veg_scale;
+  const double* veg_ext;
+  const double* veg_fsd;
+  const double* veg_contact_fraction;
+  // spectral, (nspec, ntotlay) or (nspec, ncol)
+  const double* air_ext;
+  const double* air_ssa;
+  const double* veg_ssa;
+  // SW
+  const double* ground_albedo;
+  const double* ground_albedo_dir;   // resolved: = ground_albedo unless use_sw_direct_albedo
+  const double* roof_albedo;
+  const double* roof_albedo_dir;     // resolved: = roof_albedo when not allocated
+  const double* wall_albedo;
+  const double* wall_specular_frac;
+  // LW
+  const double* clear_air_planck;
+  const double* veg_planck;
+  const double* veg_air_planck;
+  const double* ground_emissivity;
+  const double* roof_emissivity;
+  const double* wall_emissivity;
+  const double* ground_emission;
+  const double* roof_emission;
+  const double* wall_emission;
+};
+
+// Everything one launch of a layer / column kernel needs (passed by value).
+struct Launch {
+  Inputs in;
+  LG lg;
+  Cfg cfg;
+  const int32_t* cols;   // column indices (0-based) of this chunk of the class
+  int ncols;             // columns in the chunk
+  int nspec;             // spectral bands (nsw or nlw)
+  int ncu;               // column units = ncols * nspec
+  int maxlay;            // largest nlay in the chunk
+  double* lay;           // layer-matrix scratch  [layer][elem][cu]
+  double* col;           // adding-method scratch [layer][elem][cu]
+  double* top1;          // bc_out: sw_albedo / lw_emissivity   (nspec, ncol)
+  double* top2;          // bc_out: sw_albedo_dir / lw_emission (nspec, ncol)
+  FluxDev flux_a;        // sw_norm_dir  / lw_internal
+  FluxDev flux_b;        // sw_norm_diff / lw_norm
+  unsigned long long* eigen_fail;   // count of non-converged eigenproblems
+};
+
+// element (i,j) of a column-major matrix with R rows
+#define SS_E(a, i, j, R) ((a)[(i) + (j) * (R)])
+
+SS_HD double ss_sign(double a, double b) { return copysign(fabs(a), b); }
+SS_HD double ss_max(double a, double b) { return a > b ? a : b; }   // Fortran max
+SS_HD double ss_min(double a, double b) { return a < b ? a : b; }
+
+}  // namespace ss

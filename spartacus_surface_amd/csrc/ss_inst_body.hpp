@@ -1,0 +1,51 @@
+// ss_inst_body.hpp - body shared by the inst_*.hip units.  The including file
+// defines SS_INST_URBAN (true/false), SS_INST_NREG (1..3), SS_INST_LW (0/1)
+// and SS_INST_NAME (launcher symbol).
+#include "ss_kernels.hpp"
+#include "ss_solver_lw.hpp"
+#include "ss_solver_sw.hpp"
+
+namespace ss {
+namespace {
+
+template <bool U, int R, int NS, bool LW>
+__global__ void __launch_bounds__(kBlock) k_layer(const Launch L) {
+  const int cu = blockIdx.x * kBlock + threadIdx.x;
+  if (cu >= L.ncu) return;
+  if (LW) layer_unit_lw<U, R, NS>(L, cu, (int)blockIdx.y);
+  else layer_unit_sw<U, R, NS>(L, cu, (int)blockIdx.y);
+}
+
+template <bool U, int R, int NS, bool LW>
+__global__ void __launch_bounds__(kBlock) k_column(const Launch L) {
+  const int cu = blockIdx.x * kBlock + threadIdx.x;
+  if (cu >= L.ncu) return;
+  if (LW) column_unit_lw<U, R, NS>(L, cu);
+  else column_unit_sw<U, R, NS>(L, cu);
+}
+
+template <int NS>
+void launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev) {
+  const unsigned gx = (unsigned)((L.ncu + kBlock - 1) / kBlock);
+  if (ev) hipEventRecord(ev[0], stream);
+  hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx, (unsigned)L.maxlay),
+                     dim3(kBlock), 0, stream, L);
+  if (ev) hipEventRecord(ev[1], stream);
+  hipLaunchKernelGGL((k_column<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx), dim3(kBlock), 0,
+                     stream, L);
+  if (ev) hipEventRecord(ev[2], stream);
+}
+
+}  // namespace
+
+void SS_INST_NAME(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev) {
+  switch (ns) {
+    case 1: launch_ns<1>(L, stream, ev); break;
+    case 2: launch_ns<2>(L, stream, ev); break;
+    case 4: launch_ns<4>(L, stream, ev); break;
+    case 8: launch_ns<8>(L, stream, ev); break;
+    default: break;
+  }
+}
+
+}  // namespace ss

@@ -1,0 +1,34 @@
+// ss_kernels.hpp - __global__ wrappers of the per-unit bodies and the launch
+// interface between the C-ABI translation unit (ss_capi.hip) and the
+// per-class instantiation units (inst_*.hip, one per (tile kind, regions,
+// spectral region) so that hipcc can build them in parallel).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "ss_common.hpp"
+#include "ss_misc_units.hpp"
+
+namespace ss {
+
+constexpr int kBlock = 64;   // one wavefront per workgroup: no LDS sharing, no barriers
+
+// Implemented once per (urban, nreg) in inst_*.hip; ns selects the instance.
+// Launches the layer kernel over (ncu x maxlay) units, then the column kernel
+// over ncu units, on "stream"; ev[0..2] (optional) are recorded before the
+// layer kernel, between the two kernels and after the column kernel.
+using SolverLauncher = void (*)(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev);
+
+#define SS_DECL_LAUNCHER(name) void name(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev)
+SS_DECL_LAUNCHER(launch_sw_forest_r2);
+SS_DECL_LAUNCHER(launch_sw_forest_r3);
+SS_DECL_LAUNCHER(launch_sw_urban_r1);
+SS_DECL_LAUNCHER(launch_sw_urban_r2);
+SS_DECL_LAUNCHER(launch_sw_urban_r3);
+SS_DECL_LAUNCHER(launch_lw_forest_r2);
+SS_DECL_LAUNCHER(launch_lw_forest_r3);
+SS_DECL_LAUNCHER(launch_lw_urban_r1);
+SS_DECL_LAUNCHER(launch_lw_urban_r2);
+SS_DECL_LAUNCHER(launch_lw_urban_r3);
+
+}  // namespace ss

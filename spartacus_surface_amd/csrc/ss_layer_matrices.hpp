@@ -1,0 +1,391 @@
+// ss_layer_matrices.hpp - per-lane layer matrices of one (column, band, layer)
+// unit: calc_matrices_sw_eig (radtool/radtool_calc_matrices_sw_eig.F90:30-298)
+// and calc_matrices_lw_eig (radtool/radtool_calc_matrices_lw_eig.F90:32-230),
+// with schur_invert_sw (radtool/radtool_schur.F90:32-53).
+//
+// Same mathematics as the reference (Hogan 2019 Eqs. 45-49, 56-59), re-ordered
+// for a register-resident lane:
+//  * the direct-beam particular solutions g3, g4 (sw_eig :231-253) are computed
+//    FIRST, while only the Gamma matrices are live;
+//  * the (2n+d) x (2n+d) system of direct_diffuse_part (:303-386) is never
+//    formed: its matrix is block upper-triangular,
+//        [ G1   G2D  g3*e ]   [c1]   [0]
+//        [ G2D  G1   g4   ] * [c2] = [0]      => c3 = G0^-1
+//        [ 0    0    G0   ]   [c3]   [I]
+//    and the remaining 2n x 2n block has exactly the structure already solved
+//    for the diffuse R/T (Schur complement S = G1 - G2D G1^-1 G2D, whose
+//    inverse is C'_lower).  Unpivoted LU of the full matrix (what the reference
+//    does) performs this very elimination, so results agree to rounding while
+//    the 15x15 (n=6) / 27x27 (n=12) matrix and its 2/3 N^3 flops disappear;
+//  * every LU factorisation is computed once and reused.
+// Results are written straight to the HBM scratch record of the unit through a
+// writer, embedded in the full (NF x NF) layout with zero fill when the unit is
+// a clear-only or vegetation-only sub-problem (radsurf_forest_sw.F90:408-455).
+#pragma once
+
+#include "ss_common.hpp"
+#include "ss_linalg.hpp"
+#include "ss_eigen.hpp"
+
+namespace ss {
+
+// Element offsets inside one layer record of the scratch [layer][elem][cu]
+template <int NF, int DF>
+struct SwRec {
+  static constexpr int R = 0;                    // ref_diff        NF x NF
+  static constexpr int T = R + NF * NF;          // trans_diff      NF x NF
+  static constexpr int SUP = T + NF * NF;        // ref_dir         NF x DF
+  static constexpr int SDN = SUP + NF * DF;      // trans_dir_diff  NF x DF
+  static constexpr int EDIR = SDN + NF * DF;     // trans_dir_dir   DF x DF
+  static constexpr int IDIR = EDIR + DF * DF;    // int_dir         DF x DF
+  static constexpr int IDIFF = IDIR + DF * DF;   // int_diff        NF x NF
+  static constexpr int IDD = IDIFF + NF * NF;    // int_dir_diff    NF x DF
+  static constexpr int NELEM = IDD + NF * DF;
+};
+
+template <int NF>
+struct LwRec {
+  static constexpr int R = 0;                    // ref       NF x NF
+  static constexpr int T = R + NF * NF;          // trans     NF x NF
+  static constexpr int IFLUX = T + NF * NF;      // int_flux_mat NF x NF
+  static constexpr int SRC = IFLUX + NF * NF;    // source_lay   NF
+  static constexpr int ISRC = SRC + NF;          // int_source   NF
+  static constexpr int NELEM = ISRC + NF;
+};
+
+// Writer of one scratch record: element e of this unit lives at rec[e * stride]
+struct RecWriter {
+  double* rec;
+  long stride;
+  SS_HD void put(int e, double v) const { rec[(long)e * stride] = v; }
+};
+
+// Write an (RS x CS) block held in registers into the (RF x CF) matrix that
+// starts at element "off", at block position (I0, J0); everything else zero.
+template <int RF, int CF, int RS, int CS, int I0, int J0>
+SS_HD void put_embedded(const RecWriter& w, int off, const double* blk) {
+  SS_UNROLL_N(CF)
+  for (int j = 0; j < CF; ++j) {
+    SS_UNROLL_N(RF)
+    for (int i = 0; i < RF; ++i) {
+      const bool inside = (i >= I0) && (i < I0 + RS) && (j >= J0) && (j < J0 + CS);
+      w.put(off + i + j * RF, inside ? SS_E(blk, i - I0, j - J0, RS) : 0.0);
+    }
+  }
+}
+
+template <int N>
+SS_HD void scale_cols(const double* A, const double* v, double* B) {
+  SS_UNROLL_N(N)
+  for (int j = 0; j < N; ++j) {
+    SS_UNROLL_N(N)
+    for (int i = 0; i < N; ++i) SS_E(B, i, j, N) = SS_E(A, i, j, N) * v[j];
+  }
+}
+
+// Diffuse part shared by SW and LW (sw_eig :180-221, lw_eig :142-176).
+// On return: G1, G2 = eigenvector blocks, lam, e = exp(-lam dz),
+// LUG1 = lu_factor(G1), Clo = C'_lower, Cup = C'_upper; R and T are written.
+template <int N>
+struct Diffuse {
+  double G1[N * N], G2[N * N], LUG1[N * N], Clo[N * N], Cup[N * N];
+  double lam[N], e[N];
+};
+
+template <int N, class PutR, class PutT>
+SS_HD int diffuse_part(const double* g1, const double* g2, double dz, Diffuse<N>& w,
+                       const PutR& putR, const PutT& putT) {
+  double GD[N * N], P[N * N], X[N * N], ev[N];
+  int ierr;
+  {
+    double GS[N * N];
+    SS_UNROLL_NN(N)
+    for (int k = 0; k < N * N; ++k) {
+      GD[k] = g1[k] - g2[k];
+      GS[k] = g1[k] + g2[k];
+    }
+    mat_mul<N, N, N>(GD, GS, P);
+  }
+  ierr = eigen_decomposition_real<N>(P, ev, X);
+  SS_UNROLL_N(N)
+  for (int j = 0; j < N; ++j) {
+    w.lam[j] = sqrt(ss_max(0.0, ev[j]));
+    w.e[j] = exp(-w.lam[j] * dz);
+  }
+  // tmp = -(GD^-1 X) diag(lam);  G1 = X + tmp, G2 = X - tmp
+  lu_factor<N>(GD);
+  mat_copy<N, N>(X, P);
+  lu_solve_mat<N, N>(GD, P);
+  SS_UNROLL_N(N)
+  for (int j = 0; j < N; ++j) {
+    SS_UNROLL_N(N)
+    for (int i = 0; i < N; ++i) {
+      const double t = -SS_E(P, i, j, N) * w.lam[j];
+      SS_E(w.G1, i, j, N) = SS_E(X, i, j, N) + t;
+      SS_E(w.G2, i, j, N) = SS_E(X, i, j, N) - t;
+    }
+  }
+  // Eq. 48 by Schur complement
+  mat_copy<N, N>(w.G1, w.LUG1);
+  lu_factor<N>(w.LUG1);
+  {
+    double G2D[N * N], t1[N * N];
+    scale_cols<N>(w.G2, w.e, G2D);
+    mat_copy<N, N>(G2D, t1);
+    lu_solve_mat<N, N>(w.LUG1, t1);            // G1^-1 G2D
+    mat_mul<N, N, N>(G2D, t1, P);               // G2D G1^-1 G2D
+    SS_UNROLL_NN(N)
+    for (int k = 0; k < N * N; ++k) P[k] = w.G1[k] - P[k];
+    lu_factor<N>(P);
+    lu_invert<N>(P, w.Clo);                     // C'_lower = S^-1
+    mat_mul<N, N, N>(G2D, w.Clo, w.Cup);
+    lu_solve_mat<N, N>(w.LUG1, w.Cup);
+    SS_UNROLL_NN(N)
+    for (int k = 0; k < N * N; ++k) w.Cup[k] = -w.Cup[k];   // C'_upper
+    // Eq. 49: R = G1D Cup + G2 Clo ; T = G2 Cup + G1D Clo
+    double G1D[N * N];
+    scale_cols<N>(w.G1, w.e, G1D);
+    mat_mul<N, N, N>(G1D, w.Cup, t1);
+    mat_mul_acc<N, N, N>(w.G2, w.Clo, t1);
+    putR(t1);
+    mat_mul<N, N, N>(w.G2, w.Cup, t1);
+    mat_mul_acc<N, N, N>(G1D, w.Clo, t1);
+    putT(t1);
+  }
+  return ierr;
+}
+
+// calc_matrices_sw_eig for an (N, D) sub-problem embedded at (I0 = stream
+// offset, R0 = region offset) of the full (NF, DF) record.
+template <int NF, int DF, int N, int D, int I0, int R0>
+SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
+                           const double* g3, double dz, const RecWriter& w) {
+  using Rec = SwRec<NF, DF>;
+  int ierr = 0;
+  double mu[D], G0[D * D], G0inv[D * D], emu[D];
+  double g3v[N * D], g4v[N * D];   // particular solutions, one column per direct eigenvalue
+
+  // Section 3 (:223-229): E = G0 diag(exp(mu dz)) G0^-1
+  ierr += eigen_decomposition_real<D>(g0, mu, G0);
+  {
+    double LU0[D * D], t[D * D];
+    mat_copy<D, D>(G0, LU0);
+    lu_factor<D>(LU0);
+    lu_invert<D>(LU0, G0inv);
+    SS_UNROLL_N(D)
+    for (int j = 0; j < D; ++j) emu[j] = exp(mu[j] * dz);
+    scale_cols<D>(G0, emu, t);
+    double Ed[D * D];
+    mat_mul<D, D, D>(t, G0inv, Ed);
+    put_embedded<DF, DF, D, D, R0, R0>(w, Rec::EDIR, Ed);
+  }
+
+  // Section 4 (:231-253): g3, g4 for each direct eigenvalue
+  {
+    double g3g0[N * D];
+    mat_mul<N, D, D>(g3, G0, g3g0);
+    SS_UNROLL_N(D)
+    for (int jd = 0; jd < D; ++jd) {
+      double LUd[N * N], K[N * N], M[N * N];
+      mat_copy<N, N>(g1, LUd);
+      SS_UNROLL_N(N)
+      for (int jo = 0; jo < N; ++jo) SS_E(LUd, jo, jo, N) += mu[jd];
+      lu_factor<N>(LUd);                       // gamma1_d = gamma1 + mu I
+      lu_invert<N>(LUd, M);
+      mat_mul<N, N, N>(g2, M, K);               // gamma2 gamma1_d^-1
+      mat_mul<N, N, N>(K, g2, M);
+      SS_UNROLL_NN(N)
+      for (int k = 0; k < N * N; ++k) M[k] = g1[k] - M[k];
+      SS_UNROLL_N(N)
+      for (int jo = 0; jo < N; ++jo) {
+        SS_E(M, jo, jo, N) -= mu[jd];
+        SS_E(K, jo, jo, N) -= 1.0;
+      }
+      double* g4c = g4v + jd * N;
+      double* g3c = g3v + jd * N;
+      mat_vec<N, N>(K, g3g0 + jd * N, g4c);
+      lu_factor<N>(M);
+      lu_solve<N>(M, g4c);
+      mat_vec<N, N>(g2, g4c, g3c);
+      SS_UNROLL_N(N)
+      for (int i = 0; i < N; ++i) g3c[i] = g3g0[jd * N + i] + g3c[i];
+      lu_solve<N>(LUd, g3c);
+      SS_UNROLL_N(N)
+      for (int i = 0; i < N; ++i) g3c[i] = -g3c[i];
+    }
+  }
+
+  // Sections 1-2: diffuse R, T
+  Diffuse<N> df;
+  ierr += diffuse_part<N>(
+      g1, g2, dz, df,
+      [&](const double* R) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::R, R); },
+      [&](const double* T) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::T, T); });
+
+  // direct_diffuse_part (:303-386) by block elimination (see header comment)
+  {
+    double b1[N * D], b2[N * D], c1[N * D], c2[N * D], t[N * D];
+    {
+      double g3e[N * D];
+      SS_UNROLL_N(D)
+      for (int j = 0; j < D; ++j) {
+        SS_UNROLL_N(N)
+        for (int i = 0; i < N; ++i) SS_E(g3e, i, j, N) = SS_E(g3v, i, j, N) * emu[j];
+      }
+      mat_mul<N, D, D>(g3e, G0inv, b1);    // = -(rhs of block 1)
+      mat_mul<N, D, D>(g4v, G0inv, b2);    // = -(rhs of block 2)
+    }
+    double G2D[N * N];
+    scale_cols<N>(df.G2, df.e, G2D);
+    // c2 = S^-1 (-b2 + G2D G1^-1 b1)
+    mat_copy<N, D>(b1, t);
+    lu_solve_mat<N, D>(df.LUG1, t);
+    mat_mul<N, N, D>(G2D, t, c1);
+    SS_UNROLL_FULL
+    for (int k = 0; k < N * D; ++k) c1[k] = c1[k] - b2[k];
+    mat_mul<N, N, D>(df.Clo, c1, c2);
+    // c1 = G1^-1 (-b1 - G2D c2)
+    mat_mul<N, N, D>(G2D, c2, c1);
+    SS_UNROLL_FULL
+    for (int k = 0; k < N * D; ++k) c1[k] = -b1[k] - c1[k];
+    lu_solve_mat<N, D>(df.LUG1, c1);
+    // S_up = G1D c1 + G2 c2 + g3 G0^-1 ; S_dn = G2 c1 + G1D c2 + (g4 e) G0^-1
+    double G1D[N * N];
+    scale_cols<N>(df.G1, df.e, G1D);
+    mat_mul<N, N, D>(G1D, c1, t);
+    mat_mul_acc<N, N, D>(df.G2, c2, t);
+    mat_mul_acc<N, D, D>(g3v, G0inv, t);
+    put_embedded<NF, DF, N, D, I0, R0>(w, Rec::SUP, t);
+    mat_mul<N, N, D>(df.G2, c1, t);
+    mat_mul_acc<N, N, D>(G1D, c2, t);
+    {
+      double g4e[N * D];
+      SS_UNROLL_N(D)
+      for (int j = 0; j < D; ++j) {
+        SS_UNROLL_N(N)
+        for (int i = 0; i < N; ++i) SS_E(g4e, i, j, N) = SS_E(g4v, i, j, N) * emu[j];
+      }
+      mat_mul_acc<N, D, D>(g4e, G0inv, t);
+    }
+    put_embedded<NF, DF, N, D, I0, R0>(w, Rec::SDN, t);
+  }
+
+  // schur_invert_sw (radtool_schur.F90:45-51) -> int_dir, int_diff, int_dir_diff
+  {
+    double g0i[D * D];
+    {
+      double LU0[D * D];
+      mat_copy<D, D>(g0, LU0);
+      lu_factor<D>(LU0);
+      lu_invert<D>(LU0, g0i);
+      double idir[D * D];
+      SS_UNROLL_FULL
+      for (int k = 0; k < D * D; ++k) idir[k] = -g0i[k];
+      put_embedded<DF, DF, D, D, R0, R0>(w, Rec::IDIR, idir);
+    }
+    double LU1[N * N], g1i[N * N], g2i[N * N], t[N * N];
+    mat_copy<N, N>(g1, LU1);
+    lu_factor<N>(LU1);
+    mat_copy<N, N>(g2, t);
+    lu_solve_mat<N, N>(LU1, t);                 // g1^-1 g2
+    mat_mul<N, N, N>(g2, t, g2i);
+    SS_UNROLL_NN(N)
+    for (int k = 0; k < N * N; ++k) g2i[k] = g1[k] - g2i[k];
+    lu_factor<N>(g2i);
+    lu_invert<N>(g2i, g1i);                     // g1i = (g1 - g2 g1^-1 g2)^-1
+    lu_invert<N>(LU1, t);                       // g1^-1
+    mat_mul<N, N, N>(g2, t, LU1);               // g2 g1^-1
+    mat_mul<N, N, N>(g1i, LU1, g2i);            // g2i
+    SS_UNROLL_NN(N)
+    for (int k = 0; k < N * N; ++k) t[k] = g2i[k] - g1i[k];
+    put_embedded<NF, NF, N, N, I0, I0>(w, Rec::IDIFF, t);      // int_diff = g2i - g1i
+    // g3i = (g1i - g2i) (g3 g0i);  int_dir_diff = 2 g3i = -2 t (g3 g0i)
+    double u[N * D], v[N * D];
+    mat_mul<N, D, D>(g3, g0i, u);
+    mat_mul<N, N, D>(t, u, v);
+    SS_UNROLL_FULL
+    for (int k = 0; k < N * D; ++k) v[k] = -2.0 * v[k];
+    put_embedded<NF, DF, N, D, I0, R0>(w, Rec::IDD, v);
+  }
+  return ierr;
+}
+
+// calc_matrices_lw_eig for an N sub-problem embedded at stream offset I0.
+template <int NF, int N, int I0>
+SS_HD int calc_matrices_lw(const double* g1, const double* g2, const double* b, double dz,
+                           const RecWriter& w) {
+  using Rec = LwRec<NF>;
+  Diffuse<N> df;
+  int ierr = diffuse_part<N>(
+      g1, g2, dz, df,
+      [&](const double* R) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::R, R); },
+      [&](const double* T) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::T, T); });
+
+  // Section 3 (:178-195): inv_gamma_b
+  double igb[N];
+  {
+    double LU1[N * N], K[N * N], M[N * N];
+    mat_copy<N, N>(g1, LU1);
+    lu_factor<N>(LU1);
+    lu_invert<N>(LU1, M);
+    mat_mul<N, N, N>(g2, M, K);                 // gamma2 gamma1^-1
+    mat_mul<N, N, N>(K, g2, M);
+    SS_UNROLL_NN(N)
+    for (int k = 0; k < N * N; ++k) M[k] = g1[k] - M[k];
+    SS_UNROLL_N(N)
+    for (int jo = 0; jo < N; ++jo) SS_E(K, jo, jo, N) -= 1.0;
+    mat_vec<N, N>(K, b, igb);
+    lu_factor<N>(M);
+    lu_solve<N>(M, igb);
+  }
+  // Section 4 (:198-209): cb' and the source
+  double cb[N], v[N];
+  {
+    double t[N];
+    vec_copy<N>(igb, t);
+    lu_solve<N>(df.LUG1, t);                    // g1^-1 inv_gamma_b
+    double G2D[N * N];
+    scale_cols<N>(df.G2, df.e, G2D);
+    mat_vec<N, N>(G2D, t, v);
+    SS_UNROLL_N(N)
+    for (int i = 0; i < N; ++i) v[i] = igb[i] - v[i];
+    mat_vec<N, N>(df.Clo, v, cb);
+    SS_UNROLL_N(N)
+    for (int i = 0; i < N; ++i) cb[i] = -cb[i];
+    // source = (G1D + G2) cb' + inv_gamma_b
+    scale_cols<N>(df.G1, df.e, G2D);
+    SS_UNROLL_NN(N)
+    for (int k = 0; k < N * N; ++k) G2D[k] += df.G2[k];
+    mat_vec<N, N>(G2D, cb, v);
+    SS_UNROLL_N(NF)
+    for (int i = 0; i < NF; ++i) {
+      const bool inside = (i >= I0) && (i < I0 + N);
+      w.put(Rec::SRC + i, inside ? v[i - I0] + igb[i - I0] : 0.0);
+    }
+  }
+  // Section 5 (:211-227): integrated fluxes
+  {
+    double z[N], GZ[N * N], CS[N * N], IF[N * N];
+    SS_UNROLL_N(N)
+    for (int j = 0; j < N; ++j) z[j] = (1.0 - df.e[j]) / df.lam[j];
+    SS_UNROLL_N(N)
+    for (int j = 0; j < N; ++j) {
+      SS_UNROLL_N(N)
+      for (int i = 0; i < N; ++i)
+        SS_E(GZ, i, j, N) = SS_E(df.G1, i, j, N) * z[j] + SS_E(df.G2, i, j, N) * z[j];
+    }
+    SS_UNROLL_NN(N)
+    for (int k = 0; k < N * N; ++k) CS[k] = df.Clo[k] + df.Cup[k];
+    mat_mul<N, N, N>(GZ, CS, IF);
+    put_embedded<NF, NF, N, N, I0, I0>(w, Rec::IFLUX, IF);
+    mat_vec<N, N>(GZ, cb, v);
+    SS_UNROLL_N(NF)
+    for (int i = 0; i < NF; ++i) {
+      const bool inside = (i >= I0) && (i < I0 + N);
+      w.put(Rec::ISRC + i, inside ? 2.0 * (v[i - I0] + igb[i - I0] * dz) : 0.0);
+    }
+  }
+  return ierr;
+}
+
+}  // namespace ss

@@ -1,0 +1,152 @@
+// ss_misc_units.hpp - the cheap per-column paths of radsurf():
+//   flat_unit       : flat tiles, closed form (radsurf_interface.F90:122-173)
+//   zero_unit       : zero_canopy_flux of one column (radsurf_canopy_flux.F90:286-341),
+//                     used for night-time columns (radsurf_interface.F90:193-196)
+//   simple_spectrum_lw units: calc_simple_spectrum_lw
+//                     (radsurf_simple_spectrum.F90:41-66), the pre-step of the LW path
+#pragma once
+
+#include "ss_common.hpp"
+
+namespace ss {
+
+struct MiscLaunch {
+  Inputs in;
+  const int32_t* cols;
+  int ncols;
+  int nsw, nlw;
+  int do_sw, do_lw;
+  double* sw_albedo;
+  double* sw_albedo_dir;
+  double* lw_emissivity;
+  double* lw_emission;
+  FluxDev sw_dir, sw_diff, lw_int, lw_norm;
+};
+
+// one flat column
+SS_HD void flat_unit(const MiscLaunch& M, int i) {
+  const int col = M.cols[i];
+#define PUT(fd, F, idx, v) do { if ((fd).f[F]) (fd).f[F][idx] = (v); } while (0)
+  if (M.do_sw) {
+    for (int b = 0; b < M.nsw; ++b) {
+      const long c = (long)b + (long)M.nsw * col;
+      const double ga = M.in.ground_albedo[c], gad = M.in.ground_albedo_dir[c];
+      M.sw_albedo[c] = ga;
+      M.sw_albedo_dir[c] = gad;
+      PUT(M.sw_dir, F_GROUND_DN_DIR, c, 1.0);
+      PUT(M.sw_dir, F_GROUND_DN, c, 1.0);
+      PUT(M.sw_dir, F_GROUND_NET, c, 1.0 - gad);
+      PUT(M.sw_dir, F_GROUND_VERTICAL_DIFF, c, 0.5 * gad);
+      PUT(M.sw_dir, F_TOP_DN_DIR, c, 1.0);
+      PUT(M.sw_dir, F_TOP_DN, c, 1.0);
+      PUT(M.sw_dir, F_TOP_NET, c, 1.0 - gad);
+      PUT(M.sw_diff, F_GROUND_DN_DIR, c, 0.0);
+      PUT(M.sw_diff, F_GROUND_DN, c, 1.0);
+      PUT(M.sw_diff, F_GROUND_NET, c, 1.0 - ga);
+      PUT(M.sw_diff, F_GROUND_VERTICAL_DIFF, c, 0.5 * (1.0 + ga));
+      PUT(M.sw_diff, F_TOP_DN_DIR, c, 0.0);
+      PUT(M.sw_diff, F_TOP_DN, c, 1.0);
+      PUT(M.sw_diff, F_TOP_NET, c, 1.0 - ga);
+    }
+  }
+  if (M.do_lw) {
+    for (int b = 0; b < M.nlw; ++b) {
+      const long c = (long)b + (long)M.nlw * col;
+      const double em = M.in.ground_emissivity[c], emission = M.in.ground_emission[c];
+      M.lw_emissivity[c] = em;
+      M.lw_emission[c] = emission;
+      PUT(M.lw_int, F_GROUND_DN, c, 0.0);
+      PUT(M.lw_int, F_GROUND_NET, c, -emission);
+      PUT(M.lw_int, F_GROUND_VERTICAL_DIFF, c, 0.5 * emission);
+      PUT(M.lw_int, F_TOP_DN, c, 0.0);
+      PUT(M.lw_int, F_TOP_NET, c, -emission);
+      PUT(M.lw_norm, F_GROUND_DN, c, 1.0);
+      PUT(M.lw_norm, F_GROUND_NET, c, em);
+      PUT(M.lw_norm, F_GROUND_VERTICAL_DIFF, c, 0.5 * (2.0 - em));
+      PUT(M.lw_norm, F_TOP_DN, c, 1.0);
+      PUT(M.lw_norm, F_TOP_NET, c, em);
+    }
+  }
+#undef PUT
+}
+
+// Shape class of every canopy_flux member: 0 (nspec,ncol), 1 (nspec,ntotlay),
+// 2 (ncol), 3 (ntotlay)
+SS_HD int flux_field_shape(int F) {
+  switch (F) {
+    case F_GROUND_DN: case F_GROUND_DN_DIR: case F_GROUND_NET: case F_TOP_DN:
+    case F_TOP_DN_DIR: case F_TOP_NET: case F_GROUND_VERTICAL_DIFF:
+      return 0;
+    case F_GROUND_SUNLIT_FRAC:
+      return 2;
+    case F_ROOF_SUNLIT_FRAC: case F_WALL_SUNLIT_FRAC: case F_VEG_SUNLIT_FRAC:
+      return 3;
+    default:
+      return 1;
+  }
+}
+
+// zero() of one column in one flux object
+SS_HD void zero_unit(const Inputs& in, const FluxDev& f, int nspec, int col) {
+  const int nlay = in.nlay[col];
+  const int l0 = in.istartlay[col] - 1;
+  for (int F = 0; F < F_NFIELDS; ++F) {
+    double* a = f.f[F];
+    if (!a) continue;
+    const int shape = flux_field_shape(F);
+    if (shape == 0) {
+      for (int b = 0; b < nspec; ++b) a[(long)b + (long)nspec * col] = 0.0;
+    } else if (shape == 2) {
+      a[col] = 0.0;
+    } else if (shape == 1) {
+      for (int l = l0; l < l0 + nlay; ++l)
+        for (int b = 0; b < nspec; ++b) a[(long)b + (long)nspec * l] = 0.0;
+    } else {
+      for (int l = l0; l < l0 + nlay; ++l) a[l] = 0.0;
+    }
+  }
+}
+
+// calc_simple_spectrum_lw: per-column and per-layer parts
+struct SpectrumLaunch {
+  const double* ground_temperature;
+  const double* roof_temperature;
+  const double* wall_temperature;
+  const double* clear_air_temperature;
+  const double* veg_temperature;
+  const double* veg_air_temperature;
+  const double* ground_emissivity;
+  const double* roof_emissivity;
+  const double* wall_emissivity;
+  double* ground_emission;
+  double* roof_emission;
+  double* wall_emission;
+  double* clear_air_planck;
+  double* veg_planck;
+  double* veg_air_planck;
+  int col0, ncols;     // 0-based first column, count
+  int lay0, nlays;     // 0-based first layer, count
+  int do_vegetation;
+};
+
+SS_HD double pow4(double t) { return (t * t) * (t * t); }
+
+SS_HD void spectrum_col_unit(const SpectrumLaunch& S, int i) {
+  const int c = S.col0 + i;
+  S.ground_emission[c] = kStefanBoltzmann * S.ground_emissivity[c] * pow4(S.ground_temperature[c]);
+}
+
+SS_HD void spectrum_lay_unit(const SpectrumLaunch& S, int i) {
+  const int l = S.lay0 + i;
+  if (S.roof_emission) {
+    S.roof_emission[l] = kStefanBoltzmann * S.roof_emissivity[l] * pow4(S.roof_temperature[l]);
+    S.wall_emission[l] = kStefanBoltzmann * S.wall_emissivity[l] * pow4(S.wall_temperature[l]);
+  }
+  S.clear_air_planck[l] = kStefanBoltzmann * pow4(S.clear_air_temperature[l]);
+  if (S.do_vegetation) {
+    S.veg_planck[l] = kStefanBoltzmann * pow4(S.veg_temperature[l]);
+    S.veg_air_planck[l] = kStefanBoltzmann * pow4(S.veg_air_temperature[l]);
+  }
+}
+
+}  // namespace ss

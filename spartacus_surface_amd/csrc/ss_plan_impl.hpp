@@ -1,0 +1,675 @@
+// ss_plan_impl.hpp - host-side plan: column classification, HBM layout, chunked
+// launches.  Templated on a Backend so that the identical host logic drives
+//   * HipBackend  (ss_capi.hip)      - the product: HIP kernels on gfx950
+//   * EmulBackend (tests/emul)       - TEST-ONLY host loops over the same
+//                                      per-unit bodies (sanitizers, gdb)
+//
+// Column classes.  radsurf() dispatches per column on the tile type
+// (radsurf_interface.F90:105-311).  Here the columns of the requested range are
+// sorted once into classes (tile kind, number of regions, number of streams);
+// every class is one template instance of the solver kernels, so a wavefront
+// never mixes matrix orders.  Within a class columns keep their original order
+// (stable) sorted by descending layer count, so that lanes of a wave have equal
+// trip counts and idle layer-units fall into whole waves that exit at once.
+//
+// HBM layout.  Inputs and outputs are byte-for-byte mirrors of the host
+// (Fortran) arrays, (nspec, ncol) / (nspec, ntotlay) with the band index
+// fastest.  The per-layer matrices live in two scratch buffers
+// [layer][element][column-unit]; column-unit = (column of the chunk, band) with
+// the band fastest.  A class is processed in chunks of columns so that the
+// scratch stays bounded (default 4 GiB, env SPARTACUS_SCRATCH_MB).
+#pragma once
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/spartacus_surface_hip.h"
+#include "ss_common.hpp"
+#include "ss_layer_matrices.hpp"
+#include "ss_misc_units.hpp"
+#include "ss_solver_lw.hpp"
+#include "ss_solver_sw.hpp"
+
+namespace ss {
+
+struct ClassKey {
+  bool urban;
+  int nreg;
+  int ns;
+  bool operator<(const ClassKey& o) const {
+    if (urban != o.urban) return urban < o.urban;
+    if (nreg != o.nreg) return nreg < o.nreg;
+    return ns < o.ns;
+  }
+};
+
+struct ColumnClass {
+  ClassKey key;
+  std::vector<int32_t> cols;   // 0-based, sorted by nlay descending (stable)
+  size_t dev_offset = 0;       // offset of cols in the device index buffer
+  int maxlay = 0;
+};
+
+inline bool key_supported(const ClassKey& k) {
+  const bool ns_ok = (k.ns == 1 || k.ns == 2 || k.ns == 4 || k.ns == 8);
+  const bool nreg_ok = k.urban ? (k.nreg >= 1 && k.nreg <= 3) : (k.nreg == 2 || k.nreg == 3);
+  return ns_ok && nreg_ok;
+}
+
+// Number of scratch elements per layer of a class
+inline int lay_nelem(bool lw, const ClassKey& k) {
+  const int n = k.nreg * k.ns, d = k.nreg;
+  return lw ? 3 * n * n + 2 * n : 3 * n * n + 3 * n * d + 2 * d * d;
+}
+inline int col_nelem(bool lw, const ClassKey& k) {
+  const int n = k.nreg * k.ns, d = k.nreg;
+  return lw ? 3 * n * n + 2 * n : 3 * n * n + 2 * n * d;
+}
+
+// Runtime (urban, nreg, ns) -> template instance
+#define SS_DISPATCH_NS(URB, NREG, ns, CALL)                 \
+  switch (ns) {                                             \
+    case 1: { constexpr int NS_ = 1; CALL(URB, NREG, NS_); } break; \
+    case 2: { constexpr int NS_ = 2; CALL(URB, NREG, NS_); } break; \
+    case 4: { constexpr int NS_ = 4; CALL(URB, NREG, NS_); } break; \
+    case 8: { constexpr int NS_ = 8; CALL(URB, NREG, NS_); } break; \
+    default: break;                                         \
+  }
+#define SS_DISPATCH(key, CALL)                                         \
+  do {                                                                 \
+    if ((key).urban) {                                                 \
+      if ((key).nreg == 1) { SS_DISPATCH_NS(true, 1, (key).ns, CALL) } \
+      else if ((key).nreg == 2) { SS_DISPATCH_NS(true, 2, (key).ns, CALL) } \
+      else if ((key).nreg == 3) { SS_DISPATCH_NS(true, 3, (key).ns, CALL) } \
+    } else {                                                           \
+      if ((key).nreg == 2) { SS_DISPATCH_NS(false, 2, (key).ns, CALL) } \
+      else if ((key).nreg == 3) { SS_DISPATCH_NS(false, 3, (key).ns, CALL) } \
+    }                                                                  \
+  } while (0)
+
+template <class Backend>
+class Plan {
+ public:
+  ss_config cfg;
+  int ncol = 0, ntotlay = 0, nsw = 0, nlw = 0;
+  int istartcol = 1, iendcol = 0;
+  int lay_first = 0, lay_count = 0;   // packed layer range of the column range (0-based)
+  bool want_profiles = true;
+
+  // host copies of the small integer arrays (classification, slices)
+  std::vector<int32_t> h_nlay, h_istartlay, h_irep;
+  std::vector<double> h_cos_sza;
+
+  // device mirrors by name
+  std::map<std::string, void*> dev;
+  std::map<std::string, size_t> dev_elems;
+
+  std::vector<ColumnClass> sw_classes, lw_classes;
+  std::vector<int32_t> flat_cols, night_cols, lwzero_urban_cols;
+  int32_t* d_index = nullptr;
+  size_t flat_off = 0, night_off = 0;
+  size_t index_elems = 0;
+
+  double* d_lay = nullptr;
+  double* d_col = nullptr;
+  size_t scratch_budget_bytes = 0;
+  size_t lay_bytes = 0, col_bytes = 0;
+  unsigned long long* d_eigen_fail = nullptr;
+
+  typename Backend::Timers timers;
+  std::string error;
+
+  ~Plan() { release(); }
+
+  void release() {
+    for (auto& kv : dev) Backend::free(kv.second);
+    dev.clear();
+    dev_elems.clear();
+    if (d_index) Backend::free(d_index);
+    if (d_lay) Backend::free(d_lay);
+    if (d_col) Backend::free(d_col);
+    if (d_eigen_fail) Backend::free(d_eigen_fail);
+    d_index = nullptr; d_lay = d_col = nullptr; d_eigen_fail = nullptr;
+    timers.release();
+  }
+
+  // ---- device mirrors ----
+  double* darr(const char* name) const {
+    auto it = dev.find(name);
+    return it == dev.end() ? nullptr : static_cast<double*>(it->second);
+  }
+  void ensure(const std::string& name, size_t elems, size_t elsize = sizeof(double)) {
+    auto it = dev.find(name);
+    if (it != dev.end() && dev_elems[name] == elems) return;
+    if (it != dev.end()) Backend::free(it->second);
+    void* p = Backend::alloc(elems * elsize);
+    Backend::memset(p, 0, elems * elsize);
+    dev[name] = p;
+    dev_elems[name] = elems;
+  }
+  void mirror(const std::string& name, const void* host, size_t elems, size_t elsize = sizeof(double)) {
+    if (!host) {
+      auto it = dev.find(name);
+      if (it != dev.end()) { Backend::free(it->second); dev.erase(it); dev_elems.erase(name); }
+      return;
+    }
+    ensure(name, elems, elsize);
+    Backend::h2d(dev[name], host, elems * elsize);
+  }
+
+  // which canopy_flux members exist (allocate_canopy_flux, radsurf_canopy_flux.F90:96-163)
+  bool flux_member_present(int F, bool use_direct) const {
+    switch (F) {
+      case F_GROUND_DN_DIR: case F_TOP_DN_DIR: case F_GROUND_SUNLIT_FRAC:
+        return use_direct;
+      case F_ROOF_IN: case F_ROOF_NET: case F_WALL_IN: case F_WALL_NET:
+        return cfg.do_urban != 0;
+      case F_ROOF_IN_DIR: case F_WALL_IN_DIR: case F_ROOF_SUNLIT_FRAC: case F_WALL_SUNLIT_FRAC:
+        return cfg.do_urban != 0 && use_direct;
+      case F_VEG_ABS: case F_VEG_AIR_ABS:
+        return cfg.do_vegetation != 0;
+      case F_VEG_ABS_DIR: case F_VEG_SUNLIT_FRAC:
+        return cfg.do_vegetation != 0 && use_direct;
+      case F_FLUX_DN_LAYER_TOP: case F_FLUX_UP_LAYER_TOP: case F_FLUX_DN_LAYER_BASE:
+      case F_FLUX_UP_LAYER_BASE:
+        return want_profiles;
+      case F_FLUX_DN_DIR_LAYER_TOP: case F_FLUX_DN_DIR_LAYER_BASE:
+        return want_profiles && use_direct;
+      default:
+        return true;
+    }
+  }
+  static const char* flux_field_name(int F) {
+    static const char* names[F_NFIELDS] = {
+        "ground_dn", "ground_dn_dir", "ground_net", "top_dn", "top_dn_dir", "top_net",
+        "roof_in", "roof_in_dir", "roof_net", "wall_in", "wall_in_dir", "wall_net",
+        "roof_sunlit_frac", "wall_sunlit_frac", "ground_sunlit_frac", "ground_vertical_diff",
+        "clear_air_abs", "veg_abs", "veg_air_abs", "veg_abs_dir", "veg_sunlit_frac",
+        "flux_dn_layer_top", "flux_dn_dir_layer_top", "flux_up_layer_top",
+        "flux_dn_layer_base", "flux_dn_dir_layer_base", "flux_up_layer_base"};
+    return names[F];
+  }
+  size_t flux_field_elems(int F, int nspec) const {
+    switch (flux_field_shape(F)) {
+      case 0: return (size_t)nspec * ncol;
+      case 1: return (size_t)nspec * ntotlay;
+      case 2: return (size_t)ncol;
+      default: return (size_t)ntotlay;
+    }
+  }
+  FluxDev flux_dev(const char* obj) const {
+    FluxDev f;
+    for (int F = 0; F < F_NFIELDS; ++F)
+      f.f[F] = darr((std::string(obj) + "." + flux_field_name(F)).c_str());
+    return f;
+  }
+  void alloc_flux(const char* obj, int nspec, bool use_direct) {
+    for (int F = 0; F < F_NFIELDS; ++F)
+      if (flux_member_present(F, use_direct))
+        ensure(std::string(obj) + "." + flux_field_name(F), std::max<size_t>(1, flux_field_elems(F, nspec)));
+  }
+
+  // ---- creation ----
+  int create(const ss_config* c, const ss_canopy* can, const ss_sw_spectral* sw,
+             const ss_lw_spectral* lw, int i0, int i1, int profiles) {
+    cfg = *c;
+    ncol = can->ncol;
+    ntotlay = can->ntotlay;
+    nsw = c->nsw;
+    nlw = c->nlw;
+    istartcol = i0;
+    iendcol = i1;
+    want_profiles = profiles != 0;
+    if (i0 < 1 || i1 > ncol || i1 < i0 - 1) { error = "column range out of bounds"; return SS_ERR_BAD_ARGUMENT; }
+    if (cfg.do_sw && (!sw || sw->nspec != nsw)) { error = "sw spectral properties missing / nspec mismatch"; return SS_ERR_BAD_ARGUMENT; }
+    if (cfg.do_lw && (!lw || lw->nspec != nlw)) { error = "lw spectral properties missing / nspec mismatch"; return SS_ERR_BAD_ARGUMENT; }
+    const char* mb = std::getenv("SPARTACUS_SCRATCH_MB");
+    scratch_budget_bytes = (mb ? (size_t)std::atol(mb) : (size_t)4096) << 20;
+
+    ensure("bc_out.sw_albedo", std::max<size_t>(1, (size_t)nsw * ncol));
+    ensure("bc_out.sw_albedo_dir", std::max<size_t>(1, (size_t)nsw * ncol));
+    ensure("bc_out.lw_emissivity", std::max<size_t>(1, (size_t)nlw * ncol));
+    ensure("bc_out.lw_emission", std::max<size_t>(1, (size_t)nlw * ncol));
+    if (cfg.do_sw) { alloc_flux("sw_norm_dir", nsw, true); alloc_flux("sw_norm_diff", nsw, true); }
+    if (cfg.do_lw) { alloc_flux("lw_internal", nlw, false); alloc_flux("lw_norm", nlw, false); }
+    d_eigen_fail = static_cast<unsigned long long*>(Backend::alloc(sizeof(unsigned long long)));
+    Backend::memset(d_eigen_fail, 0, sizeof(unsigned long long));
+    return upload(can, sw, lw);
+  }
+
+  // ---- upload inputs + classify ----
+  int upload(const ss_canopy* can, const ss_sw_spectral* sw, const ss_lw_spectral* lw) {
+    if (can->ncol != ncol || can->ntotlay != ntotlay) { error = "shape changed since plan creation"; return SS_ERR_BAD_ARGUMENT; }
+    h_nlay.assign(can->nlay, can->nlay + ncol);
+    h_istartlay.assign(can->istartlay, can->istartlay + ncol);
+    h_irep.assign(can->i_representation, can->i_representation + ncol);
+    if (can->cos_sza) h_cos_sza.assign(can->cos_sza, can->cos_sza + ncol);
+    else h_cos_sza.assign(ncol, 0.0);
+
+    mirror("canopy.nlay", can->nlay, ncol, sizeof(int32_t));
+    mirror("canopy.istartlay", can->istartlay, ncol, sizeof(int32_t));
+    mirror("canopy.cos_sza", can->cos_sza, ncol);
+    const size_t nl = std::max(1, ntotlay);
+#define MIRL(obj, member) mirror(#obj "." #member, (obj)->member, (obj)->member ? nl : 0)
+    mirror("canopy.dz", can->dz, nl);
+    mirror("canopy.building_fraction", can->building_fraction, nl);
+    mirror("canopy.veg_fraction", can->veg_fraction, nl);
+    mirror("canopy.building_scale", can->building_scale, nl);
+    mirror("canopy.veg_scale", can->veg_scale, nl);
+    mirror("canopy.veg_ext", can->veg_ext, nl);
+    mirror("canopy.veg_fsd", can->veg_fsd, nl);
+    mirror("canopy.veg_contact_fraction", can->veg_contact_fraction, nl);
+    mirror("canopy.ground_temperature", can->ground_temperature, ncol);
+    mirror("canopy.roof_temperature", can->roof_temperature, nl);
+    mirror("canopy.wall_temperature", can->wall_temperature, nl);
+    mirror("canopy.clear_air_temperature", can->clear_air_temperature, nl);
+    mirror("canopy.veg_temperature", can->veg_temperature, nl);
+    mirror("canopy.veg_air_temperature", can->veg_air_temperature, nl);
+#undef MIRL
+    if (cfg.do_sw) {
+      const size_t sl = (size_t)nsw * nl, sc = (size_t)nsw * ncol;
+      mirror("sw.air_ext", sw->air_ext, sl);
+      mirror("sw.air_ssa", sw->air_ssa, sl);
+      mirror("sw.veg_ssa", sw->veg_ssa, sl);
+      mirror("sw.ground_albedo", sw->ground_albedo, sc);
+      mirror("sw.roof_albedo", sw->roof_albedo, sl);
+      mirror("sw.wall_albedo", sw->wall_albedo, sl);
+      mirror("sw.ground_albedo_dir", sw->ground_albedo_dir, sc);
+      mirror("sw.roof_albedo_dir", sw->roof_albedo_dir, sl);
+      mirror("sw.wall_specular_frac", sw->wall_specular_frac, sl);
+    }
+    if (cfg.do_lw) {
+      const size_t ll = (size_t)nlw * nl, lc = (size_t)nlw * ncol;
+      mirror("lw.air_ext", lw->air_ext, ll);
+      mirror("lw.air_ssa", lw->air_ssa, ll);
+      mirror("lw.veg_ssa", lw->veg_ssa, ll);
+      mirror("lw.clear_air_planck", lw->clear_air_planck, ll);
+      mirror("lw.veg_planck", lw->veg_planck, ll);
+      mirror("lw.veg_air_planck", lw->veg_air_planck, ll);
+      mirror("lw.ground_emissivity", lw->ground_emissivity, lc);
+      mirror("lw.roof_emissivity", lw->roof_emissivity, ll);
+      mirror("lw.wall_emissivity", lw->wall_emissivity, ll);
+      mirror("lw.ground_emission", lw->ground_emission, lc);
+      mirror("lw.roof_emission", lw->roof_emission, ll);
+      mirror("lw.wall_emission", lw->wall_emission, ll);
+    }
+    return classify();
+  }
+
+  int classify() {
+    sw_classes.clear(); lw_classes.clear();
+    flat_cols.clear(); night_cols.clear();
+    std::map<ClassKey, std::vector<int32_t>> swm, lwm;
+    lay_first = 0; lay_count = 0;
+    for (int j = istartcol - 1; j < iendcol; ++j) {
+      const int irep = h_irep[j];
+      if (irep == SS_TILE_FLAT) { flat_cols.push_back(j); continue; }
+      if (irep == SS_TILE_SIMPLE_URBAN || irep == SS_TILE_INFINITE_STREET) {
+        if (h_nlay[j] > 1) { error = "simple urban representations must have only one layer"; return SS_ERR_SIMPLE_URBAN_LAYERS; }
+        error = "tile types 4/5 (simple urban) are not on the device path";
+        return SS_ERR_TILE_NOT_ON_DEVICE;
+      }
+      if (irep < 0 || irep > 5) { error = "bad surface type"; return SS_ERR_BAD_ARGUMENT; }
+      const bool urban = irep != SS_TILE_FOREST;
+      const int nreg = (irep == SS_TILE_FOREST) ? cfg.n_vegetation_region_forest + 1
+                       : (irep == SS_TILE_URBAN) ? 1 : cfg.n_vegetation_region_urban + 1;
+      if (urban && nreg > 1 && !cfg.do_vegetation) { error = "urban tile with >1 region but do_vegetation off"; return SS_ERR_VEG_DISABLED; }
+      if (h_nlay[j] < 1) { error = "canopy column without layers"; return SS_ERR_BAD_ARGUMENT; }
+      if (cfg.do_sw) {
+        if (h_cos_sza[j] > 0.0) {
+          ClassKey k{urban, nreg, urban ? cfg.lg_sw_urban.nstream : cfg.lg_sw_forest.nstream};
+          if (!key_supported(k)) { error = "SW (nstream,nregion) combination not instantiated"; return SS_ERR_UNSUPPORTED; }
+          swm[k].push_back(j);
+        } else {
+          night_cols.push_back(j);
+        }
+      }
+      if (cfg.do_lw) {
+        ClassKey k{urban, nreg, urban ? cfg.lg_lw_urban.nstream : cfg.lg_lw_forest.nstream};
+        if (!key_supported(k)) { error = "LW (nstream,nregion) combination not instantiated"; return SS_ERR_UNSUPPORTED; }
+        lwm[k].push_back(j);
+      }
+    }
+    if (iendcol >= istartcol) {
+      lay_first = h_istartlay[istartcol - 1] - 1;
+      // last canopy column of the range defines the end of the layer slice
+      int last = lay_first;
+      for (int j = istartcol - 1; j < iendcol; ++j)
+        if (h_irep[j] != SS_TILE_FLAT) last = std::max(last, h_istartlay[j] - 1 + h_nlay[j]);
+      lay_count = last - lay_first;
+    }
+    auto finish = [&](std::map<ClassKey, std::vector<int32_t>>& m, std::vector<ColumnClass>& out) {
+      for (auto& kv : m) {
+        ColumnClass cc;
+        cc.key = kv.first;
+        cc.cols = kv.second;
+        std::stable_sort(cc.cols.begin(), cc.cols.end(),
+                         [&](int32_t a, int32_t b) { return h_nlay[a] > h_nlay[b]; });
+        cc.maxlay = h_nlay[cc.cols.front()];
+        out.push_back(std::move(cc));
+      }
+    };
+    finish(swm, sw_classes);
+    finish(lwm, lw_classes);
+
+    // one device index buffer: [sw classes][lw classes][flat][night]
+    std::vector<int32_t> idx;
+    for (auto& c : sw_classes) { c.dev_offset = idx.size(); idx.insert(idx.end(), c.cols.begin(), c.cols.end()); }
+    for (auto& c : lw_classes) { c.dev_offset = idx.size(); idx.insert(idx.end(), c.cols.begin(), c.cols.end()); }
+    flat_off = idx.size(); idx.insert(idx.end(), flat_cols.begin(), flat_cols.end());
+    night_off = idx.size(); idx.insert(idx.end(), night_cols.begin(), night_cols.end());
+    if (idx.empty()) idx.push_back(0);
+    if (!d_index || index_elems < idx.size()) {
+      if (d_index) Backend::free(d_index);
+      d_index = static_cast<int32_t*>(Backend::alloc(idx.size() * sizeof(int32_t)));
+      index_elems = idx.size();
+    }
+    Backend::h2d(d_index, idx.data(), idx.size() * sizeof(int32_t));
+
+    // scratch sizing: the largest per-column need over all classes
+    size_t need_lay = 0, need_col = 0;
+    auto account = [&](const std::vector<ColumnClass>& cls, bool lw, int nspec) {
+      for (auto& c : cls) {
+        const size_t per_col = (size_t)nspec * c.maxlay * sizeof(double);
+        const size_t tot = per_col * (lay_nelem(lw, c.key) + col_nelem(lw, c.key));
+        size_t chunk = std::max<size_t>(1, scratch_budget_bytes / std::max<size_t>(1, tot));
+        chunk = std::min(chunk, c.cols.size());
+        need_lay = std::max(need_lay, chunk * per_col * lay_nelem(lw, c.key));
+        need_col = std::max(need_col, chunk * per_col * col_nelem(lw, c.key));
+      }
+    };
+    account(sw_classes, false, nsw);
+    account(lw_classes, true, nlw);
+    if (need_lay > lay_bytes) { if (d_lay) Backend::free(d_lay); d_lay = static_cast<double*>(Backend::alloc(need_lay)); lay_bytes = need_lay; }
+    if (need_col > col_bytes) { if (d_col) Backend::free(d_col); d_col = static_cast<double*>(Backend::alloc(need_col)); col_bytes = need_col; }
+    return SS_OK;
+  }
+
+  // ---- building the launch descriptors ----
+  static LG make_lg(const ss_legendre_gauss& g) {
+    LG l;
+    for (int i = 0; i < kDevMaxStreams; ++i) {
+      const bool on = i < g.nstream;
+      l.mu[i] = on ? g.mu[i] : 1.0;
+      l.tan_ang[i] = on ? g.tan_ang[i] : 0.0;
+      l.weight[i] = on ? g.weight[i] : 0.0;
+      l.hweight[i] = on ? g.hweight[i] : 0.0;
+      l.vweight[i] = on ? g.vweight[i] : 0.0;
+    }
+    l.vadjustment = g.vadjustment;
+    l.vadjustment2 = g.vadjustment2;
+    return l;
+  }
+
+  Inputs make_inputs(bool lw) const {
+    Inputs in;
+    std::memset(&in, 0, sizeof(in));
+    in.nlay = static_cast<const int32_t*>(dev.at("canopy.nlay"));
+    in.istartlay = static_cast<const int32_t*>(dev.at("canopy.istartlay"));
+    in.cos_sza = darr("canopy.cos_sza");
+    in.dz = darr("canopy.dz");
+    in.building_fraction = darr("canopy.building_fraction");
+    in.veg_fraction = darr("canopy.veg_fraction");
+    in.building_scale = darr("canopy.building_scale");
+    in.veg_scale = darr("canopy.veg_scale");
+    in.veg_ext = darr("canopy.veg_ext");
+    in.veg_fsd = darr("canopy.veg_fsd");
+    in.veg_contact_fraction = darr("canopy.veg_contact_fraction");
+    const std::string p = lw ? "lw." : "sw.";
+    in.air_ext = darr((p + "air_ext").c_str());
+    in.air_ssa = darr((p + "air_ssa").c_str());
+    in.veg_ssa = darr((p + "veg_ssa").c_str());
+    // both spectral families are filled (the flat / misc kernels need both)
+    in.ground_albedo = darr("sw.ground_albedo");
+    // ground_sw_albedo_dir pointer choice of radsurf_interface.F90:98-102
+    in.ground_albedo_dir = cfg.use_sw_direct_albedo ? darr("sw.ground_albedo_dir") : darr("sw.ground_albedo");
+    in.roof_albedo = darr("sw.roof_albedo");
+    // radsurf_urban_sw.F90:631-643: roof_albedo_dir if allocated, else roof_albedo
+    in.roof_albedo_dir = darr("sw.roof_albedo_dir") ? darr("sw.roof_albedo_dir") : darr("sw.roof_albedo");
+    in.wall_albedo = darr("sw.wall_albedo");
+    in.wall_specular_frac = darr("sw.wall_specular_frac");
+    in.clear_air_planck = darr("lw.clear_air_planck");
+    in.veg_planck = darr("lw.veg_planck");
+    in.veg_air_planck = darr("lw.veg_air_planck");
+    in.ground_emissivity = darr("lw.ground_emissivity");
+    in.roof_emissivity = darr("lw.roof_emissivity");
+    in.wall_emissivity = darr("lw.wall_emissivity");
+    in.ground_emission = darr("lw.ground_emission");
+    in.roof_emission = darr("lw.roof_emission");
+    in.wall_emission = darr("lw.wall_emission");
+    return in;
+  }
+
+  // Inputs a class needs must be present (the reference would dereference an
+  // unallocated array)
+  int check_inputs(const ClassKey& k, bool lw) {
+    auto need = [&](const char* n) {
+      if (!darr(n)) { error = std::string("required input array not provided: ") + n; return false; }
+      return true;
+    };
+    bool ok = need("canopy.dz");
+    const std::string p = lw ? "lw." : "sw.";
+    ok = ok && need((p + "air_ext").c_str()) && need((p + "air_ssa").c_str());
+    if (k.nreg > 1) {
+      ok = ok && need("canopy.veg_fraction") && need("canopy.veg_scale") && need("canopy.veg_ext")
+           && need((p + "veg_ssa").c_str());
+      if (k.nreg == 3) ok = ok && need("canopy.veg_fsd");
+      if (lw) ok = ok && need("lw.veg_planck") && need("lw.veg_air_planck");
+    }
+    if (k.urban) {
+      ok = ok && need("canopy.building_fraction") && need("canopy.building_scale");
+      if (k.nreg > 1) ok = ok && need("canopy.veg_contact_fraction");
+      if (lw) ok = ok && need("lw.roof_emissivity") && need("lw.wall_emissivity") && need("lw.roof_emission") && need("lw.wall_emission");
+      else ok = ok && need("sw.roof_albedo") && need("sw.wall_albedo") && need("sw.wall_specular_frac");
+    }
+    if (lw) ok = ok && need("lw.clear_air_planck") && need("lw.ground_emissivity") && need("lw.ground_emission");
+    else ok = ok && need("sw.ground_albedo") && need("canopy.cos_sza")
+              && (!cfg.use_sw_direct_albedo || need("sw.ground_albedo_dir"));
+    return ok ? SS_OK : SS_ERR_BAD_ARGUMENT;
+  }
+
+  Launch make_launch(const ColumnClass& c, bool lw, size_t first, size_t count, int chunk_maxlay) const {
+    Launch L;
+    L.in = make_inputs(lw);
+    const bool urban = c.key.urban;
+    L.lg = make_lg(lw ? (urban ? cfg.lg_lw_urban : cfg.lg_lw_forest)
+                      : (urban ? cfg.lg_sw_urban : cfg.lg_sw_forest));
+    L.cfg.min_vegetation_fraction = cfg.min_vegetation_fraction;
+    L.cfg.min_building_fraction = cfg.min_building_fraction;
+    L.cfg.vegetation_isolation_factor = urban ? cfg.vegetation_isolation_factor_urban
+                                              : cfg.vegetation_isolation_factor_forest;
+    L.cfg.use_symmetric_vegetation_scale = urban ? cfg.use_symmetric_vegetation_scale_urban
+                                                 : cfg.use_symmetric_vegetation_scale_forest;
+    L.cfg.do_vegetation = cfg.do_vegetation;
+    L.cols = d_index + c.dev_offset + first;
+    L.ncols = (int)count;
+    L.nspec = lw ? nlw : nsw;
+    L.ncu = L.ncols * L.nspec;
+    L.maxlay = chunk_maxlay;
+    L.lay = d_lay;
+    L.col = d_col;
+    L.top1 = darr(lw ? "bc_out.lw_emissivity" : "bc_out.sw_albedo");
+    L.top2 = darr(lw ? "bc_out.lw_emission" : "bc_out.sw_albedo_dir");
+    L.flux_a = flux_dev(lw ? "lw_internal" : "sw_norm_dir");
+    L.flux_b = flux_dev(lw ? "lw_norm" : "sw_norm_diff");
+    L.eigen_fail = d_eigen_fail;
+    return L;
+  }
+
+  MiscLaunch make_misc(size_t off, size_t count) const {
+    MiscLaunch M;
+    M.in = make_inputs(false);
+    M.cols = d_index + off;
+    M.ncols = (int)count;
+    M.nsw = nsw; M.nlw = nlw;
+    M.do_sw = cfg.do_sw; M.do_lw = cfg.do_lw;
+    M.sw_albedo = darr("bc_out.sw_albedo");
+    M.sw_albedo_dir = darr("bc_out.sw_albedo_dir");
+    M.lw_emissivity = darr("bc_out.lw_emissivity");
+    M.lw_emission = darr("bc_out.lw_emission");
+    M.sw_dir = flux_dev("sw_norm_dir");
+    M.sw_diff = flux_dev("sw_norm_diff");
+    M.lw_int = flux_dev("lw_internal");
+    M.lw_norm = flux_dev("lw_norm");
+    return M;
+  }
+
+  // ---- one pass of the hot path ----
+  int solve() {
+    timers.begin_solve();
+    Backend::memset_async(d_eigen_fail, 0, sizeof(unsigned long long));
+    if (!flat_cols.empty()) {
+      if (cfg.do_sw && (!darr("sw.ground_albedo"))) { error = "sw.ground_albedo missing"; return SS_ERR_BAD_ARGUMENT; }
+      if (cfg.do_lw && (!darr("lw.ground_emissivity") || !darr("lw.ground_emission"))) { error = "lw ground arrays missing"; return SS_ERR_BAD_ARGUMENT; }
+      Backend::launch_flat(make_misc(flat_off, flat_cols.size()), timers);
+    }
+    if (!night_cols.empty()) Backend::launch_night(make_misc(night_off, night_cols.size()), timers);
+    for (int lw = 0; lw < 2; ++lw) {
+      const auto& classes = lw ? lw_classes : sw_classes;
+      const int nspec = lw ? nlw : nsw;
+      for (const auto& c : classes) {
+        int rc = check_inputs(c.key, lw != 0);
+        if (rc) return rc;
+        const size_t per_col = (size_t)nspec * c.maxlay * sizeof(double)
+                               * (lay_nelem(lw != 0, c.key) + col_nelem(lw != 0, c.key));
+        size_t chunk = std::max<size_t>(1, scratch_budget_bytes / std::max<size_t>(1, per_col));
+        // keep chunks a multiple of the wave size where possible
+        if (chunk >= 128) chunk -= chunk % 64;
+        chunk = std::max<size_t>(1, std::min(chunk, c.cols.size()));
+        for (size_t first = 0; first < c.cols.size(); first += chunk) {
+          const size_t count = std::min(chunk, c.cols.size() - first);
+          const int chunk_maxlay = h_nlay[c.cols[first]];   // sorted descending
+          Launch L = make_launch(c, lw != 0, first, count, chunk_maxlay);
+          Backend::launch_solver(c.key, lw != 0, L, timers);
+        }
+      }
+    }
+    timers.end_solve();
+    return SS_OK;
+  }
+
+  int simple_spectrum_lw() {
+    if (!cfg.do_lw) return SS_OK;
+    if (nlw > 1) { error = "Simple longwave spectrum only possible with one input spectral interval"; return SS_ERR_BAD_ARGUMENT; }
+    if (iendcol < istartcol) return SS_OK;
+    SpectrumLaunch S;
+    std::memset(&S, 0, sizeof(S));
+    S.ground_temperature = darr("canopy.ground_temperature");
+    S.roof_temperature = darr("canopy.roof_temperature");
+    S.wall_temperature = darr("canopy.wall_temperature");
+    S.clear_air_temperature = darr("canopy.clear_air_temperature");
+    S.veg_temperature = darr("canopy.veg_temperature");
+    S.veg_air_temperature = darr("canopy.veg_air_temperature");
+    S.ground_emissivity = darr("lw.ground_emissivity");
+    S.roof_emissivity = darr("lw.roof_emissivity");
+    S.wall_emissivity = darr("lw.wall_emissivity");
+    S.ground_emission = darr("lw.ground_emission");
+    S.roof_emission = (S.roof_emissivity && S.roof_temperature) ? darr("lw.roof_emission") : nullptr;
+    S.wall_emission = darr("lw.wall_emission");
+    S.clear_air_planck = darr("lw.clear_air_planck");
+    S.veg_planck = darr("lw.veg_planck");
+    S.veg_air_planck = darr("lw.veg_air_planck");
+    S.do_vegetation = cfg.do_vegetation && S.veg_planck && S.veg_temperature && S.veg_air_temperature;
+    if (!S.ground_temperature || !S.ground_emissivity || !S.ground_emission) { error = "ground temperature/emissivity/emission arrays missing"; return SS_ERR_BAD_ARGUMENT; }
+    S.col0 = istartcol - 1;
+    S.ncols = iendcol - istartcol + 1;
+    // calc_simple_spectrum_lw: ilay1 = istartlay(istartcol), ilay2 = istartlay(iendcol)+nlay(iendcol)-1
+    S.lay0 = h_istartlay[istartcol - 1] - 1;
+    S.nlays = (h_istartlay[iendcol - 1] - 1 + h_nlay[iendcol - 1]) - S.lay0;
+    if (S.nlays > 0 && (!S.clear_air_temperature || !S.clear_air_planck)) { error = "air temperature / planck arrays missing"; return SS_ERR_BAD_ARGUMENT; }
+    Backend::launch_spectrum(S, timers);
+    return SS_OK;
+  }
+
+  // ---- download: only the slices the reference would have written ----
+  void get_cols(const char* name, double* host, int nspec) {
+    if (!host || iendcol < istartcol) return;
+    const double* d = darr(name);
+    if (!d) return;
+    const size_t off = (size_t)nspec * (istartcol - 1), n = (size_t)nspec * (iendcol - istartcol + 1);
+    Backend::d2h(host + off, d + off, n * sizeof(double));
+  }
+  void get_lays(const char* name, double* host, int nspec) {
+    if (!host || lay_count <= 0) return;
+    const double* d = darr(name);
+    if (!d) return;
+    const size_t off = (size_t)nspec * lay_first, n = (size_t)nspec * lay_count;
+    Backend::d2h(host + off, d + off, n * sizeof(double));
+  }
+  void put_cols(const char* name, const double* host, int nspec) {
+    if (!host || iendcol < istartcol) return;
+    double* d = darr(name);
+    if (!d) return;
+    const size_t off = (size_t)nspec * (istartcol - 1), n = (size_t)nspec * (iendcol - istartcol + 1);
+    Backend::h2d(d + off, host + off, n * sizeof(double));
+  }
+  void put_lays(const char* name, const double* host, int nspec) {
+    if (!host || lay_count <= 0) return;
+    double* d = darr(name);
+    if (!d) return;
+    const size_t off = (size_t)nspec * lay_first, n = (size_t)nspec * lay_count;
+    Backend::h2d(d + off, host + off, n * sizeof(double));
+  }
+  static double* const* flux_members(const ss_flux* f) { return &f->ground_dn; }
+
+  void xfer_flux(const char* obj, ss_flux* f, int nspec, bool to_host) {
+    if (!f) return;
+    double* const* m = &f->ground_dn;
+    for (int F = 0; F < F_NFIELDS; ++F) {
+      const std::string name = std::string(obj) + "." + flux_field_name(F);
+      const int shape = flux_field_shape(F);
+      const int ns = (shape == 0 || shape == 1) ? nspec : 1;
+      if (shape == 0 || shape == 2) { if (to_host) get_cols(name.c_str(), m[F], ns); else put_cols(name.c_str(), m[F], ns); }
+      else { if (to_host) get_lays(name.c_str(), m[F], ns); else put_lays(name.c_str(), m[F], ns); }
+    }
+  }
+
+  int download(ss_bc_out* bc, ss_flux* sw_dir, ss_flux* sw_diff, ss_flux* lw_int, ss_flux* lw_nrm) {
+    Backend::sync();
+    if (bc) {
+      if (cfg.do_sw) { get_cols("bc_out.sw_albedo", bc->sw_albedo, nsw); get_cols("bc_out.sw_albedo_dir", bc->sw_albedo_dir, nsw); }
+      if (cfg.do_lw) { get_cols("bc_out.lw_emissivity", bc->lw_emissivity, nlw); get_cols("bc_out.lw_emission", bc->lw_emission, nlw); }
+    }
+    if (cfg.do_sw) { xfer_flux("sw_norm_dir", sw_dir, nsw, true); xfer_flux("sw_norm_diff", sw_diff, nsw, true); }
+    if (cfg.do_lw) { xfer_flux("lw_internal", lw_int, nlw, true); xfer_flux("lw_norm", lw_nrm, nlw, true); }
+    return SS_OK;
+  }
+
+  // Seed the device outputs with the caller's current contents, so members the
+  // reference leaves untouched (e.g. bc_out SW of night-time columns,
+  // per-column members of flat tiles) round-trip unchanged.
+  int upload_outputs(const ss_bc_out* bc, ss_flux* sw_dir, ss_flux* sw_diff, ss_flux* lw_int, ss_flux* lw_nrm) {
+    if (bc) {
+      if (cfg.do_sw) { put_cols("bc_out.sw_albedo", bc->sw_albedo, nsw); put_cols("bc_out.sw_albedo_dir", bc->sw_albedo_dir, nsw); }
+      if (cfg.do_lw) { put_cols("bc_out.lw_emissivity", bc->lw_emissivity, nlw); put_cols("bc_out.lw_emission", bc->lw_emission, nlw); }
+    }
+    if (cfg.do_sw) { xfer_flux("sw_norm_dir", sw_dir, nsw, false); xfer_flux("sw_norm_diff", sw_diff, nsw, false); }
+    if (cfg.do_lw) { xfer_flux("lw_internal", lw_int, nlw, false); xfer_flux("lw_norm", lw_nrm, nlw, false); }
+    return SS_OK;
+  }
+
+  // emission / Planck arrays computed by simple_spectrum_lw go back to the host
+  void download_spectrum(const ss_lw_spectral* lw) {
+    if (!lw) return;
+    Backend::sync();
+    get_cols("lw.ground_emission", lw->ground_emission, nlw);
+    get_lays("lw.roof_emission", lw->roof_emission, nlw);
+    get_lays("lw.wall_emission", lw->wall_emission, nlw);
+    get_lays("lw.clear_air_planck", lw->clear_air_planck, nlw);
+    get_lays("lw.veg_planck", lw->veg_planck, nlw);
+    get_lays("lw.veg_air_planck", lw->veg_air_planck, nlw);
+  }
+
+  long long eigen_failures() {
+    Backend::sync();
+    unsigned long long v = 0;
+    Backend::d2h(&v, d_eigen_fail, sizeof(v));
+    return (long long)v;
+  }
+};
+
+}  // namespace ss

@@ -1,0 +1,171 @@
+"""Host-side mirror of the reference's solver entry point, bound to the HIP library.
+
+``radsurf(config, canopy_props, sw_spectral_props, lw_spectral_props, bc_out,
+istartcol, iendcol, sw_norm_dir, sw_norm_diff, lw_internal, lw_norm)`` has the
+argument list and meaning of ``radsurf_interface::radsurf``
+(radsurf/radsurf_interface.F90:20-25): the caller allocates everything, slices
+``(:, istartcol:iendcol)`` and the matching packed layer ranges of the outputs
+are written.  It goes through the C-ABI ``spartacus_radsurf_hip`` of
+``include/spartacus_surface_hip.h`` - host buffers in, host buffers out.
+
+:class:`Plan` is the device-resident form (inputs and outputs stay in HBM
+between calls) used by ``bench.py`` and by hosts that keep their fields on the
+GPU.
+
+There is NO CPU fallback: if ``libspartacus_surface_hip.so`` has not been built
+or no MI355X is visible, these raise.
+"""
+import ctypes as C
+import os
+
+from . import abi
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                         "libspartacus_surface_hip.so")
+_lib = None
+
+STATUS = {
+    1: "SS_ERR_NO_DEVICE", 2: "SS_ERR_UNSUPPORTED", 3: "SS_ERR_SIMPLE_URBAN_LAYERS",
+    4: "SS_ERR_VEG_DISABLED", 5: "SS_ERR_BAD_ARGUMENT", 6: "SS_ERR_HIP",
+    7: "SS_ERR_TILE_NOT_ON_DEVICE",
+}
+
+EXPORTS = (
+    "spartacus_radsurf_hip", "ss_plan_create", "ss_plan_upload",
+    "ss_plan_calc_simple_spectrum_lw", "ss_plan_solve", "ss_plan_synchronize",
+    "ss_plan_download", "ss_plan_last_kernel_ms", "ss_plan_eigen_failures",
+    "ss_plan_device_ptr", "ss_plan_destroy", "ss_device_count", "ss_set_device",
+    "ss_last_error", "ss_version",
+)
+
+
+class SpartacusHipError(RuntimeError):
+    pass
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen the in-tree HIP library (built by ``__graft_entry__.build()`` /
+    ``make -C spartacus_surface_amd/csrc``).  Raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise SpartacusHipError(
+                "HIP extension not built: %s is missing (run `python -c 'import "
+                "__graft_entry__ as g; g.build()'`); there is no CPU fallback" % _LIB_PATH)
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.ss_last_error.restype = C.c_char_p
+        _lib.ss_version.restype = C.c_char_p
+        for name in EXPORTS:
+            if name not in ("ss_last_error", "ss_version"):
+                getattr(_lib, name).restype = C.c_int
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        msg = load_library().ss_last_error()
+        raise SpartacusHipError("%s (%d): %s" % (STATUS.get(rc, "error"), rc,
+                                                 msg.decode() if msg else ""))
+
+
+def device_count():
+    n = C.c_int32(0)
+    load_library().ss_device_count(C.byref(n))
+    return n.value
+
+
+def set_device(index):
+    _check(load_library().ss_set_device(C.c_int32(index)))
+
+
+def _flux_ptr(f):
+    return C.byref(f.to_c()) if f is not None else None
+
+
+def radsurf(config, canopy_props, sw_spectral_props, lw_spectral_props, bc_out,
+            istartcol=None, iendcol=None, sw_norm_dir=None, sw_norm_diff=None,
+            lw_internal=None, lw_norm=None):
+    """radsurf_interface::radsurf on the MI355X (host buffers in / out)."""
+    lib = load_library()
+    if istartcol is None:
+        istartcol = 1                       # radsurf_interface.F90:86-90
+    if iendcol is None:
+        iendcol = canopy_props.ncol         # :92-96
+    keep = [config.to_c(), canopy_props.to_c(), sw_spectral_props.to_c(),
+            lw_spectral_props.to_c(), bc_out.to_c()]
+    fl = [f.to_c() if f is not None and f.nspec else None
+          for f in (sw_norm_dir, sw_norm_diff, lw_internal, lw_norm)]
+    args = [C.byref(k) for k in keep] + [C.c_int32(istartcol), C.c_int32(iendcol)]
+    args += [C.byref(f) if f is not None else None for f in fl]
+    _check(lib.spartacus_radsurf_hip(*args))
+
+
+class Plan:
+    """Device-resident column set: create -> [upload] -> solve ... -> download."""
+
+    def __init__(self, config, canopy_props, sw_spectral_props, lw_spectral_props,
+                 istartcol=1, iendcol=None, want_profiles=True):
+        self._lib = load_library()
+        self.config = config
+        self.canopy = canopy_props
+        self.sw = sw_spectral_props
+        self.lw = lw_spectral_props
+        self._h = C.c_void_p()
+        if iendcol is None:
+            iendcol = canopy_props.ncol
+        self._keep = [config.to_c(), canopy_props.to_c(), sw_spectral_props.to_c(),
+                      lw_spectral_props.to_c()]
+        _check(self._lib.ss_plan_create(C.byref(self._h), *[C.byref(k) for k in self._keep],
+                                        C.c_int32(istartcol), C.c_int32(iendcol),
+                                        C.c_int32(int(want_profiles))))
+
+    def upload(self):
+        self._keep[1:] = [self.canopy.to_c(), self.sw.to_c(), self.lw.to_c()]
+        _check(self._lib.ss_plan_upload(self._h, *[C.byref(k) for k in self._keep[1:]]))
+
+    def calc_simple_spectrum_lw(self):
+        _check(self._lib.ss_plan_calc_simple_spectrum_lw(self._h))
+
+    def solve(self):
+        _check(self._lib.ss_plan_solve(self._h))
+
+    def synchronize(self):
+        _check(self._lib.ss_plan_synchronize(self._h))
+
+    def download(self, bc_out, sw_norm_dir=None, sw_norm_diff=None, lw_internal=None,
+                 lw_norm=None):
+        keep = [bc_out.to_c()] + [f.to_c() if f is not None and f.nspec else None
+                                  for f in (sw_norm_dir, sw_norm_diff, lw_internal, lw_norm)]
+        _check(self._lib.ss_plan_download(
+            self._h, *[C.byref(k) if k is not None else None for k in keep]))
+
+    def kernel_ms(self, name):
+        ms = C.c_double(0.0)
+        _check(self._lib.ss_plan_last_kernel_ms(self._h, name.encode(), C.byref(ms)))
+        return ms.value
+
+    def eigen_failures(self):
+        n = C.c_int64(0)
+        _check(self._lib.ss_plan_eigen_failures(self._h, C.byref(n)))
+        return n.value
+
+    def device_ptr(self, name):
+        p = C.c_void_p()
+        n = C.c_int64(0)
+        _check(self._lib.ss_plan_device_ptr(self._h, name.encode(), C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def close(self):
+        if self._h:
+            self._lib.ss_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,42 @@
+"""TEST-ONLY host build of the kernel bodies (see ss_emul.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libss_emul.so")
+_lib = None
+
+CXXFLAGS = ["-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas"]
+
+
+def build(force=False, extra_flags=()):
+    src = os.path.join(HERE, "ss_emul.cpp")
+    csrc = os.path.join(HERE, "..", "..", "spartacus_surface_amd", "csrc")
+    deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
+    if (not force and os.path.exists(LIB)
+            and os.path.getmtime(LIB) >= max(os.path.getmtime(d) for d in deps)):
+        return LIB
+    subprocess.run(["g++"] + CXXFLAGS + list(extra_flags) + ["-o", LIB, src], check=True)
+    return LIB
+
+
+def run_emul(config, cp, sw, lw, want_profiles=True, do_simple_spectrum=False,
+             istartcol=1, iendcol=None, out=None):
+    from oracle import checker   # only for alloc_outputs / argument packing (test code)
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB)
+    if iendcol is None:
+        iendcol = cp.ncol
+    if out is None:
+        out = checker.alloc_outputs(config, cp, want_profiles)
+    keep, args = checker._common_args(config, cp, sw, lw, out, istartcol, iendcol)
+    nfail = C.c_longlong(0)
+    _lib.spartacus_radsurf_emul.restype = C.c_int
+    rc = _lib.spartacus_radsurf_emul(*args, C.c_int32(int(do_simple_spectrum)),
+                                     C.c_int32(int(want_profiles)), C.byref(nfail))
+    if rc != 0:
+        raise RuntimeError("emulated HIP path returned %d" % rc)
+    return out, nfail.value

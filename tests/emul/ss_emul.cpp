@@ -1,0 +1,86 @@
+// ss_emul.cpp - TEST-ONLY host build of the kernel bodies.
+//
+// The per-unit functions of spartacus_surface_amd/csrc (layer_unit_*,
+// column_unit_*, flat/zero/spectrum units) are __host__ __device__; this file
+// compiles them with g++ and drives them through the SAME host-side plan logic
+// as the HIP library (ss_plan_impl.hpp) with plain loops instead of kernel
+// launches.  Purpose: debug / sanitise the kernel arithmetic and the host logic
+// in a container without a GPU.  It is NOT a fallback: nothing in the product
+// path (libspartacus_surface_hip.so, spartacus_surface_amd.radsurf) links or
+// loads it, and it lives under tests/.
+#include <cstdlib>
+#include <cstring>
+
+#include "../../spartacus_surface_amd/csrc/ss_plan_impl.hpp"
+
+namespace {
+
+struct EmulBackend {
+  struct Timers {
+    void begin_solve() {}
+    void end_solve() {}
+    void release() {}
+  };
+  static void* alloc(size_t n) { return std::malloc(n ? n : 1); }
+  static void free(void* p) { std::free(p); }
+  static void memset(void* p, int v, size_t n) { std::memset(p, v, n); }
+  static void memset_async(void* p, int v, size_t n) { std::memset(p, v, n); }
+  static void h2d(void* d, const void* h, size_t n) { std::memcpy(d, h, n); }
+  static void d2h(void* h, const void* d, size_t n) { std::memcpy(h, d, n); }
+  static void sync() {}
+
+  static void launch_flat(const ss::MiscLaunch& M, Timers&) {
+    for (int i = 0; i < M.ncols; ++i) ss::flat_unit(M, i);
+  }
+  static void launch_night(const ss::MiscLaunch& M, Timers&) {
+    for (int i = 0; i < M.ncols; ++i) {
+      ss::zero_unit(M.in, M.sw_dir, M.nsw, M.cols[i]);
+      ss::zero_unit(M.in, M.sw_diff, M.nsw, M.cols[i]);
+    }
+  }
+  static void launch_spectrum(const ss::SpectrumLaunch& S, Timers&) {
+    for (int i = 0; i < S.ncols; ++i) ss::spectrum_col_unit(S, i);
+    for (int i = 0; i < S.nlays; ++i) ss::spectrum_lay_unit(S, i);
+  }
+  template <bool U, int R, int NS>
+  static void run(bool lw, const ss::Launch& L) {
+    for (int jlay = 0; jlay < L.maxlay; ++jlay)
+      for (int cu = 0; cu < L.ncu; ++cu) {
+        if (lw) ss::layer_unit_lw<U, R, NS>(L, cu, jlay);
+        else ss::layer_unit_sw<U, R, NS>(L, cu, jlay);
+      }
+    for (int cu = 0; cu < L.ncu; ++cu) {
+      if (lw) ss::column_unit_lw<U, R, NS>(L, cu);
+      else ss::column_unit_sw<U, R, NS>(L, cu);
+    }
+  }
+  static void launch_solver(const ss::ClassKey& key, bool lw, const ss::Launch& L, Timers&) {
+#define EMUL_CALL(U, R, NS) run<U, R, NS>(lw, L)
+    SS_DISPATCH(key, EMUL_CALL);
+#undef EMUL_CALL
+  }
+};
+
+}  // namespace
+
+extern "C" int spartacus_radsurf_emul(const ss_config* config, const ss_canopy* canopy,
+                                      const ss_sw_spectral* sw, const ss_lw_spectral* lw,
+                                      ss_bc_out* bc_out, int32_t istartcol, int32_t iendcol,
+                                      ss_flux* sw_norm_dir, ss_flux* sw_norm_diff,
+                                      ss_flux* lw_internal, ss_flux* lw_norm,
+                                      int32_t do_simple_spectrum, int32_t want_profiles,
+                                      long long* eigen_failures) {
+  ss::Plan<EmulBackend> plan;
+  int rc = plan.create(config, canopy, sw, lw, istartcol, iendcol, want_profiles);
+  if (rc) return rc;
+  plan.upload_outputs(bc_out, sw_norm_dir, sw_norm_diff, lw_internal, lw_norm);
+  if (do_simple_spectrum) {
+    rc = plan.simple_spectrum_lw();
+    if (rc) return rc;
+    plan.download_spectrum(lw);
+  }
+  rc = plan.solve();
+  if (rc) return rc;
+  if (eigen_failures) *eigen_failures = plan.eigen_failures();
+  return plan.download(bc_out, sw_norm_dir, sw_norm_diff, lw_internal, lw_norm);
+}

@@ -47,8 +47,12 @@ def pack_case(case, outputs=None, want_profiles=True):
     return d
 
 
-def save_case(path, case, outputs, want_profiles=True):
-    np.savez_compressed(path, **pack_case(case, outputs, want_profiles))
+def save_case(path, case, outputs, want_profiles=True, noise=None):
+    d = pack_case(case, outputs, want_profiles)
+    if noise is not None:
+        for k, v in noise.items():
+            d["noise." + k] = np.float64(v)
+    np.savez_compressed(path, **d)
 
 
 def load_case(path):
@@ -63,7 +67,7 @@ def load_case(path):
     cp = CanopyProperties()
     sw = SwSpectralProperties(nspec=cfg.nsw)
     lw = LwSpectralProperties(nspec=cfg.nlw)
-    expected, drv = {}, {}
+    expected, drv, noise = {}, {}, {}
     for k in z.files:
         if k.startswith("canopy."):
             setattr(cp, k[7:], np.array(z[k]))
@@ -75,13 +79,15 @@ def load_case(path):
             drv[k[7:]] = np.array(z[k])
         elif k.startswith("out."):
             expected[k[4:]] = np.array(z[k])
+        elif k.startswith("noise."):
+            noise[k[6:]] = float(z[k])
     cp.ncol = int(cp.nlay.size)
     cp.ntotlay = int(cp.nlay.sum())
     sw.ncol = lw.ncol = cp.ncol
     sw.ntotlay = lw.ntotlay = cp.ntotlay
     cp.normalise(); sw.normalise(); lw.normalise()
     case = dict(config=cfg, canopy=cp, sw=sw, lw=lw, do_simple_spectrum=do_simple,
-                want_profiles=want_profiles, **drv)
+                want_profiles=want_profiles, ref_noise=noise, **drv)
     return case, expected
 
 
@@ -98,20 +104,69 @@ def flatten_outputs(outputs):
     return flat
 
 
-def max_rel_error(got, expected, floor=1.0e-3):
-    """Metric of SURVEY.md section 8(d): max over every output variable of
-    |got-ref| / max(|ref|, floor * max|ref of that variable|).  Returns
-    (error, name of the worst variable).  NaN anywhere -> inf."""
-    worst, where = 0.0, None
+def _object_scales(expected):
+    """Flux scale of every output object: the largest magnitude of any of its
+    members (1 for the normalized objects, since top_dn = 1; W m-2 for
+    lw_internal; per variable for bc_out)."""
+    scales = {}
     for k, ref in expected.items():
-        g = got[k]
+        obj = k.split(".")[0]
+        key = k if obj == "bc_out" else obj
+        if ref.size:
+            m = float(np.max(np.abs(ref[np.isfinite(ref)]))) if np.any(np.isfinite(ref)) else 0.0
+            scales[key] = max(scales.get(key, 0.0), m)
+    return scales
+
+
+def rel_errors(got, expected, floor=1.0e-3, zero_floor=1.0e-9):
+    """Per-variable error metric:
+        max |got - ref| / max(|ref|, floor * max|ref_v|, zero_floor * S_obj)
+    where S_obj is the flux scale of the object the variable belongs to; the
+    last term only matters for variables that are physically zero (e.g. the
+    reflected flux of a non-scattering canopy), which otherwise would be
+    compared relative to their own rounding noise.  NaN/inf anywhere -> inf."""
+    out = {}
+    scales = _object_scales(expected)
+    for k, ref in expected.items():
         if ref.size == 0:
             continue
-        scale = max(float(np.max(np.abs(ref))), 1.0e-300)
-        err = np.abs(g - ref) / np.maximum(np.abs(ref), floor * scale)
-        e = float(np.max(err)) if np.all(np.isfinite(g)) else float("inf")
-        if not np.isfinite(e):
-            e = float("inf")
-        if e > worst:
-            worst, where = e, k
-    return worst, where
+        g = got[k]
+        obj = k.split(".")[0]
+        s_obj = scales.get(k if obj == "bc_out" else obj, 0.0)
+        if not (np.all(np.isfinite(g)) and np.all(np.isfinite(ref))):
+            out[k] = float("inf")
+            continue
+        scale = float(np.max(np.abs(ref)))
+        den = np.maximum(np.maximum(np.abs(ref), floor * scale), max(zero_floor * s_obj, 1.0e-300))
+        out[k] = float(np.max(np.abs(g - ref) / den))
+    return out
+
+
+# Parity bar (BASELINE.json north_star): fluxes within 1e-5 relative of the
+# reference.  Where the reference's own fp64 result is farther than that from
+# the exact-arithmetic value of its algorithm (degenerate eigen-spectra of
+# identical regions, SURVEY.md section 7; measured per variable with the
+# binary128 build of the oracle and stored in the fixture as ref_noise), no
+# fp64 implementation can match it more closely than that noise: the bar for
+# such a variable is NOISE_FACTOR x the reference's own error.
+PARITY_TOL = 1.0e-5
+NOISE_FACTOR = 4.0
+
+
+def parity_violations(got, expected, ref_noise, tol=PARITY_TOL, noise_factor=NOISE_FACTOR):
+    """[(name, error, allowed)] for every variable outside the parity bar."""
+    bad = []
+    for k, e in rel_errors(got, expected).items():
+        allowed = max(tol, noise_factor * ref_noise.get(k, 0.0))
+        if not e <= allowed:
+            bad.append((k, e, allowed))
+    return bad
+
+
+def max_rel_error(got, expected, floor=1.0e-3):
+    """(largest per-variable error of :func:`rel_errors`, its variable)."""
+    errs = rel_errors(got, expected, floor)
+    if not errs:
+        return 0.0, None
+    k = max(errs, key=lambda n: errs[n])
+    return (errs[k], k) if errs[k] > 0.0 else (0.0, None)

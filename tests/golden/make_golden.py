@@ -31,8 +31,28 @@ def main():
         outputs, _ = checker.run_ref(case["config"], case["canopy"], case["sw"], case["lw"],
                                      want_profiles=True,
                                      do_simple_spectrum=case["do_simple_spectrum"])
+        # the reference's own rounding error per variable, against the binary128
+        # build of the restatement (exact-arithmetic yardstick)
+        truth, _ = checker.run_oracle(case["config"], case["canopy"], case["sw"], case["lw"],
+                                      want_profiles=True, quad=True, nthreads=8,
+                                      do_simple_spectrum=case["do_simple_spectrum"])
+        ref_flat = fixture_io.flatten_outputs(outputs)
+        noise = fixture_io.rel_errors(ref_flat, fixture_io.flatten_outputs(truth))
+        # ... and its sensitivity to a last-bit change of the inputs (layer
+        # thickness scaled by 1 +- few ulp), which also exposes configurations
+        # where the algorithm itself is singular (test_noscat) and the
+        # binary128 value is meaningless
+        import copy
+        for eps in (1.0e-15, -1.0e-15, 3.0e-15, -4.0e-15, 1.0e-13, -1.0e-13):
+            cp2 = copy.deepcopy(case["canopy"])
+            cp2.dz = cp2.dz * (1.0 + eps)
+            pert, _ = checker.run_oracle(case["config"], cp2, case["sw"], case["lw"],
+                                         want_profiles=True, nthreads=8,
+                                         do_simple_spectrum=case["do_simple_spectrum"])
+            for k, v in fixture_io.rel_errors(fixture_io.flatten_outputs(pert), ref_flat).items():
+                noise[k] = max(noise.get(k, 0.0), v)
         path = os.path.join(out_dir, name.replace("/", "__") + ".npz")
-        fixture_io.save_case(path, case, outputs, want_profiles=True)
+        fixture_io.save_case(path, case, outputs, want_profiles=True, noise=noise)
         total += os.path.getsize(path)
         print("%-50s %7.1f KB" % (name, os.path.getsize(path) / 1024.0))
     print("total %.2f MB" % (total / 1048576.0))

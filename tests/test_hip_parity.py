@@ -1,0 +1,207 @@
+"""Parity tests proper: the HIP path on a real MI355X, through the C-ABI
+(spartacus_radsurf_hip and the ss_plan_* entry points), against
+
+* the committed golden vectors = fp64 outputs of the real reference on every
+  input its own test suite ships (bar: fixture_io.PARITY_TOL = 1e-5 relative,
+  widened per variable only where the reference's own rounding error, measured
+  with the binary128 build of the oracle, is larger than that);
+* the CPU oracle on seeded synthetic many-column inputs (the bench workloads);
+* size-independent properties at full bench size (column independence /
+  permutation invariance, replicated columns give replicated results).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests import fixture_io
+from tests.conftest import golden_files
+
+pytestmark = pytest.mark.gpu
+
+# simple__test_noscat sets every single-scattering albedo to exactly zero, which
+# makes the reference's eigenvector route singular (G2 = X - X): its own fp64
+# output is then rounding noise for several variables (e.g. lw_norm%veg_abs is
+# 0.44 where exact arithmetic gives 0.084).  Parity there is checked on the
+# variables the reference itself gets right to 1e-3.
+REFERENCE_SINGULAR = {"simple__test_noscat": 1.0e-3}
+
+
+def _hip():
+    from spartacus_surface_amd import radsurf
+    radsurf.load_library()          # raises if the extension is missing: no fallback
+    assert radsurf.device_count() >= 1
+    return radsurf
+
+
+def _alloc(case):
+    from oracle import checker      # test-only helper for output allocation
+    return checker.alloc_outputs(case["config"], case["canopy"], case["want_profiles"])
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_golden_host_entry(path):
+    """spartacus_radsurf_hip (host buffers in/out) vs the reference's outputs."""
+    radsurf = _hip()
+    name = os.path.basename(path)[:-4]
+    case, expected = fixture_io.load_case(path)
+    cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
+    if case["do_simple_spectrum"]:
+        from spartacus_surface_amd.inputs import calc_simple_spectrum_lw
+        calc_simple_spectrum_lw(cfg, cp, lw)
+    out = _alloc(case)
+    radsurf.radsurf(cfg, cp, sw, lw, out["bc_out"], 1, cp.ncol, out["sw_norm_dir"],
+                    out["sw_norm_diff"], out["lw_internal"], out["lw_norm"])
+    got = fixture_io.flatten_outputs(out)
+    noise = dict(case["ref_noise"])
+    if name in REFERENCE_SINGULAR:
+        lim = REFERENCE_SINGULAR[name]
+        expected = {k: v for k, v in expected.items() if noise.get(k, 0.0) <= lim}
+        noise = {k: max(v, lim) for k, v in noise.items()}
+    bad = fixture_io.parity_violations(got, expected, noise)
+    assert not bad, "outside the parity bar: %s" % bad[:5]
+
+
+@pytest.mark.parametrize("name", ["simple__test_surfaces", "urban__2stream", "rami4pilps__vis-med-0.3"])
+def test_golden_plan_api_with_device_spectrum(name):
+    """ss_plan_*: upload once, calc_simple_spectrum_lw + solve on device,
+    download; solving twice gives identical results; no eigen failures."""
+    radsurf = _hip()
+    path = [p for p in golden_files() if os.path.basename(p)[:-4] == name][0]
+    case, expected = fixture_io.load_case(path)
+    cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
+    plan = radsurf.Plan(cfg, cp, sw, lw, want_profiles=True)
+    outs = []
+    for _ in range(2):
+        if case["do_simple_spectrum"]:
+            plan.calc_simple_spectrum_lw()
+        plan.solve()
+        out = _alloc(case)
+        plan.download(out["bc_out"], out["sw_norm_dir"], out["sw_norm_diff"],
+                      out["lw_internal"], out["lw_norm"])
+        outs.append(fixture_io.flatten_outputs(out))
+    assert plan.eigen_failures() == 0
+    assert plan.kernel_ms("total") > 0.0
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    bad = fixture_io.parity_violations(outs[0], expected, case["ref_noise"])
+    assert not bad, bad[:5]
+    plan.close()
+
+
+def test_column_range_slices_only():
+    """Only (:, istartcol:iendcol) and the matching layer slices are written
+    (radsurf_interface.F90:105; driver blocks, spartacus_surface_driver.F90:206-233)."""
+    radsurf = _hip()
+    path = [p for p in golden_files() if p.endswith("urban__2stream.npz")][0]
+    case, expected = fixture_io.load_case(path)
+    cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
+    out = _alloc(case)
+    sentinel = -12345.0
+    for obj in ("sw_norm_dir", "sw_norm_diff"):
+        for a in out[obj].fields().values():
+            a[...] = sentinel
+    out["bc_out"].sw_albedo[...] = sentinel
+    i0, i1 = 11, 30
+    radsurf.radsurf(cfg, cp, sw, lw, out["bc_out"], i0, i1, out["sw_norm_dir"],
+                    out["sw_norm_diff"], out["lw_internal"], out["lw_norm"])
+    got = fixture_io.flatten_outputs(out)
+    l0 = cp.istartlay[i0 - 1] - 1
+    l1 = cp.istartlay[i1 - 1] - 1 + cp.nlay[i1 - 1]
+    for k, ref in expected.items():
+        if not k.startswith(("sw_norm", "bc_out.sw_albedo")) or k == "bc_out.sw_albedo_dir":
+            continue
+        per_col = ref.shape[0] == cp.ncol
+        lo, hi = (i0 - 1, i1) if per_col else (l0, l1)
+        inside, g = ref[lo:hi], got[k][lo:hi]
+        assert np.allclose(g, inside, rtol=1e-5, atol=1e-9), k
+        outside = np.concatenate([got[k][:lo].ravel(), got[k][hi:].ravel()])
+        assert np.all(outside == sentinel), k
+
+
+def test_error_behaviour():
+    """Simple-urban tiles are not on the device path; >1 layer is the
+    reference's own fatal error (radsurf_interface.F90:281-284)."""
+    radsurf = _hip()
+    path = [p for p in golden_files() if p.endswith("single_layer__sp.npz")][0]
+    case, _ = fixture_io.load_case(path)
+    cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
+    cp.i_representation = np.full(cp.ncol, 4, dtype=np.int32)
+    out = _alloc(case)
+    with pytest.raises(radsurf.SpartacusHipError, match="TILE_NOT_ON_DEVICE"):
+        radsurf.radsurf(cfg, cp, sw, lw, out["bc_out"], 1, cp.ncol, out["sw_norm_dir"],
+                        out["sw_norm_diff"], out["lw_internal"], out["lw_norm"])
+
+
+def _check_against_oracle(case, ncheck, tol=1.0e-7):
+    from oracle import checker
+    radsurf = _hip()
+    cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
+    plan = radsurf.Plan(cfg, cp, sw, lw, want_profiles=case.get("want_profiles", False))
+    plan.solve()
+    out = checker.alloc_outputs(cfg, cp, case.get("want_profiles", False))
+    plan.download(out["bc_out"], out["sw_norm_dir"], out["sw_norm_diff"], out["lw_internal"],
+                  out["lw_norm"])
+    assert plan.eigen_failures() == 0
+    plan.close()
+    got = fixture_io.flatten_outputs(out)
+    ref_out, _ = checker.run_oracle(cfg, cp, sw, lw, want_profiles=case.get("want_profiles", False),
+                                    istartcol=1, iendcol=ncheck, nthreads=8)
+    ref = fixture_io.flatten_outputs(ref_out)
+    nl = int(cp.istartlay[ncheck - 1] - 1 + cp.nlay[ncheck - 1])
+    sl = lambda a: a[:ncheck] if a.shape[0] == cp.ncol else a[:nl]   # noqa: E731
+    err, where = fixture_io.max_rel_error({k: sl(v) for k, v in got.items()},
+                                          {k: sl(v) for k, v in ref.items()})
+    return got, err, where
+
+
+def test_synthetic_c3_vs_oracle():
+    """Bench workload C3 (vegetated urban, 3 regions x 10 layers, SW+LW) at a
+    size the oracle finishes in seconds."""
+    from spartacus_surface_amd import workloads
+    case = workloads.c3_vegetated_urban(ncol=4096, seed=12345)
+    _, err, where = _check_against_oracle(case, 4096)
+    assert err <= fixture_io.PARITY_TOL, (err, where)
+
+
+def test_synthetic_c2_vs_oracle():
+    from spartacus_surface_amd import workloads
+    case = workloads.c2_rami4pilps(ncol=4600)
+    _, err, where = _check_against_oracle(case, 4600)
+    assert err <= fixture_io.PARITY_TOL, (err, where)
+
+
+def test_synthetic_c4_mixed_multiband_vs_oracle():
+    from spartacus_surface_amd import workloads
+    case = workloads.c4_mixed(ncol=512, seed=12345)
+    _, err, where = _check_against_oracle(case, 512)
+    assert err <= fixture_io.PARITY_TOL, (err, where)
+
+
+def test_full_size_properties_c3():
+    """Size-independent properties at the full bench size (1e6 columns x 10
+    layers): (i) columns are independent, so the first 2048 columns of the big
+    run equal a 2048-column run bit for bit and the oracle to 1e-5; (ii) every
+    flux is finite; (iii) energy closes as well as in the reference
+    (ground + air + walls + roofs + vegetation - top net ~ 0)."""
+    from spartacus_surface_amd import workloads
+    big = workloads.c3_vegetated_urban(ncol=1_000_000, seed=12345)
+    got_big, err, where = _check_against_oracle(big, 2048)
+    assert err <= fixture_io.PARITY_TOL, (err, where)
+    small = workloads.c3_vegetated_urban(ncol=2048, seed=12345)
+    got_small, err_s, _ = _check_against_oracle(small, 2048)
+    cp = small["canopy"]
+    nl = int(cp.ntotlay)
+    for k, v in got_small.items():
+        head = got_big[k][:2048] if v.shape[0] == 2048 else got_big[k][:nl]
+        assert np.array_equal(head, v), k
+    for k, v in got_big.items():
+        assert np.all(np.isfinite(v)), k
+    # energy budget of the normalized direct SW fluxes, all 1e6 columns
+    cpb = big["canopy"]
+    L = int(cpb.nlay[0])
+    lay = lambda n: got_big["sw_norm_dir." + n].reshape(cpb.ncol, L, -1).sum(axis=(1, 2))   # noqa: E731
+    resid = (got_big["sw_norm_dir.ground_net"].sum(axis=1) + lay("clear_air_abs") + lay("veg_abs")
+             + lay("veg_air_abs") + lay("roof_net") + lay("wall_net")
+             - got_big["sw_norm_dir.top_net"].sum(axis=1))
+    assert np.max(np.abs(resid)) < 5.0e-3
