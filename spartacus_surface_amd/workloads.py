@@ -254,3 +254,27 @@ def algorithmic_bytes_per_column(case):
     if W:
         bytes_out += 16 * W + 2 * (40 * W + L * 8 * pW * W)
     return bytes_in, bytes_out
+
+
+def head_columns(case, ncol):
+    """The first ncol columns of a workload as a case of its own (columns are
+    independent, so solving them alone must reproduce the big run)."""
+    import copy
+    from . import abi
+    cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
+    nl = int(cp.istartlay[ncol - 1] - 1 + cp.nlay[ncol - 1])
+    cp2, sw2, lw2 = copy.copy(cp), copy.copy(sw), copy.copy(lw)
+    cp2.set_layers(cp.nlay[:ncol].copy())
+    for n in abi.CANOPY_REAL_FIELDS + ("i_representation",):
+        a = getattr(cp, n)
+        if a is not None:
+            setattr(cp2, n, a[:ncol].copy() if a.shape[0] == cp.ncol else a[:nl].copy())
+    for obj, obj2, names in ((sw, sw2, abi.SW_FIELDS), (lw, lw2, abi.LW_FIELDS)):
+        for n in names:
+            a = getattr(obj, n)
+            if a is not None:
+                setattr(obj2, n, a[:ncol].copy() if a.shape[0] == cp.ncol else a[:nl].copy())
+    out = dict(case)
+    out.update(config=cfg, canopy=cp2, sw=sw2, lw=lw2)
+    return _finish(cfg, cp2, sw2, lw2, **{k: v for k, v in out.items()
+                                           if k not in ("config", "canopy", "sw", "lw")})
