@@ -20,6 +20,7 @@ from spartacus_surface_amd.types import BoundaryCondsOut, CanopyFlux
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_LIB = os.path.join(HERE, "_ref", "libspartacus_ref.so")
+SHIM_LIB = os.path.join(HERE, "_ref", "libspartacus_shim.so")
 ORACLE_LIB = os.path.join(HERE, "liboracle.so")
 ORACLE_QUAD_LIB = os.path.join(HERE, "liboracle_quad.so")
 
@@ -115,6 +116,35 @@ def run_ref(config, cp, sw, lw, want_profiles=True, do_simple_spectrum=False,
                                    C.c_int32(int(want_profiles)), C.byref(elapsed))
     if rc != 0:
         raise RuntimeError("reference harness returned %d" % rc)
+    return out, elapsed.value
+
+
+def have_shim():
+    return os.path.exists(SHIM_LIB)
+
+
+def run_shim(config, cp, sw, lw, want_profiles=True, do_simple_spectrum=False,
+             nblocksize=None, istartcol=1, iendcol=None, out=None):
+    """The Fortran drop-in boundary end to end: the harness fills the
+    REFERENCE's derived types and calls THIS repository's module
+    radsurf_interface (ISO_C_BINDING shim), which calls the HIP library.
+    Needs a GPU.  nblocksize defaults to all columns in one call."""
+    _raise_stack_limit()
+    lib = _load(SHIM_LIB)
+    if iendcol is None:
+        iendcol = cp.ncol
+    if nblocksize is None:
+        nblocksize = max(1, cp.ncol)
+    if out is None:
+        out = alloc_outputs(config, cp, want_profiles)
+    keep, args = _common_args(config, cp, sw, lw, out, istartcol, iendcol)
+    elapsed = C.c_double(0.0)
+    lib.spartacus_radsurf_shim.restype = C.c_int
+    rc = lib.spartacus_radsurf_shim(*args, C.c_int32(nblocksize), C.c_int32(1),
+                                    C.c_int32(int(do_simple_spectrum)),
+                                    C.c_int32(int(want_profiles)), C.byref(elapsed))
+    if rc != 0:
+        raise RuntimeError("shim harness returned %d" % rc)
     return out, elapsed.value
 
 

@@ -9,11 +9,21 @@
 ! bench.py can time the reference's CPU path ("cpu_baseline.kind" =
 ! "reference").  Nothing in the product path links or calls it.
 !
+! The same source is compiled a second time against THIS repository's drop-in
+! module radsurf_interface (spartacus_surface_amd/fortran/radsurf_interface_hip.F90)
+! with -DHARNESS_ENTRY='spartacus_radsurf_shim' into
+! oracle/_ref/libspartacus_shim.so: that is the test of the Fortran boundary
+! (reference derived types -> ISO_C_BINDING shim -> HIP library).
+!
 ! It drives radsurf() in the pattern of the reference's own driver: blocks of
 ! nblocksize columns in an OpenMP PARALLEL DO SCHEDULE(RUNTIME) loop, with
 ! calc_simple_spectrum_lw before radsurf in every block, repeated nrepeat
 ! times, wall-clock around the loop only
 ! (driver/spartacus_surface_driver.F90:195-269).
+
+#ifndef HARNESS_ENTRY
+#define HARNESS_ENTRY 'spartacus_radsurf_ref'
+#endif
 
 module ref_harness_types
 
@@ -242,7 +252,7 @@ contains
   function spartacus_radsurf_ref(cc, ccan, csw, clw, cbc, istartcol_in, iendcol_in, &
        &  c_sw_dir, c_sw_diff, c_lw_int, c_lw_norm, &
        &  nblocksize, nrepeat, do_simple_spectrum, want_profiles, elapsed) &
-       &  bind(c, name='spartacus_radsurf_ref') result(istatus)
+       &  bind(c, name=HARNESS_ENTRY) result(istatus)
 
     use omp_lib
     use radsurf_config,             only : config_type

@@ -17,19 +17,45 @@
 #pragma once
 
 #include "ss_common.hpp"
+#include "ss_eigen_static.hpp"
 
 namespace ss {
+
+template <int N>
+SS_HD int eigen_decomposition_real_dynamic(const double* amat, double* eigenvalue, double* eigenvector);
+
+// Dispatch: closed forms for N <= 2 (inside the dynamic routine), the
+// register-resident form for 3 <= N <= SS_UNROLL_MAX, run-time indexed arrays
+// (scratch) above that.
+template <int N>
+SS_HD int eigen_decomposition_real(const double* amat, double* eigenvalue, double* eigenvector) {
+#ifndef SS_EIGEN_DYNAMIC_ONLY
+  if constexpr (N >= 3 && N <= SS_UNROLL_MAX) {
+    return eigen_decomposition_real_static<N>(amat, eigenvalue, eigenvector);
+  } else
+#endif
+  {
+    return eigen_decomposition_real_dynamic<N>(amat, eigenvalue, eigenvector);
+  }
+}
 
 // amat: N x N column-major (not modified).  eigenvalue: N.  eigenvector: N x N
 // (columns).  Returns 0 or the index of the eigenvalue at which the QR
 // iteration gave up (:498-510; the reference's callers ignore it).
 template <int N>
-SS_HD int eigen_decomposition_real(const double* amat, double* eigenvalue, double* eigenvector) {
+SS_HD int eigen_decomposition_real_dynamic(const double* amat, double* eigenvalue, double* eigenvector) {
   if (N == 1) {
     eigenvalue[0] = amat[0];
     eigenvector[0] = 1.0;
     return 0;
   }
+#ifdef SS_TIMING_NO_EIGEN   // timing experiment only: wrong results
+  for (int i = 0; i < N; ++i) {
+    eigenvalue[i] = amat[i + i * N];
+    for (int j = 0; j < N; ++j) eigenvector[i + j * N] = (i == j) ? 1.0 : 0.01 * amat[i + j * N];
+  }
+  return 0;
+#endif
   const double Tol = DBL_EPSILON;
   if (N == 2) {
     const double a11 = amat[0], a21 = amat[1], a12 = amat[2], a22 = amat[3];

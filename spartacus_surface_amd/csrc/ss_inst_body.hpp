@@ -2,14 +2,23 @@
 // defines SS_INST_URBAN (true/false), SS_INST_NREG (1..3), SS_INST_LW (0/1)
 // and SS_INST_NAME (launcher symbol).
 #include "ss_kernels.hpp"
+#include "ss_column_lw.hpp"
+#include "ss_column_sw.hpp"
 #include "ss_solver_lw.hpp"
 #include "ss_solver_sw.hpp"
 
 namespace ss {
 namespace {
 
+#ifndef SS_MIN_WAVES_LAYER
+#define SS_MIN_WAVES_LAYER 1
+#endif
+#ifndef SS_MIN_WAVES_COLUMN
+#define SS_MIN_WAVES_COLUMN 1
+#endif
+
 template <bool U, int R, int NS, bool LW>
-__global__ void __launch_bounds__(kBlock) k_layer(const Launch L) {
+__global__ void __launch_bounds__(kBlock, SS_MIN_WAVES_LAYER) k_layer(const Launch L) {
   const int cu = blockIdx.x * kBlock + threadIdx.x;
   if (cu >= L.ncu) return;
   if (LW) layer_unit_lw<U, R, NS>(L, cu, (int)blockIdx.y);
@@ -17,7 +26,7 @@ __global__ void __launch_bounds__(kBlock) k_layer(const Launch L) {
 }
 
 template <bool U, int R, int NS, bool LW>
-__global__ void __launch_bounds__(kBlock) k_column(const Launch L) {
+__global__ void __launch_bounds__(kBlock, SS_MIN_WAVES_COLUMN) k_column(const Launch L) {
   const int cu = blockIdx.x * kBlock + threadIdx.x;
   if (cu >= L.ncu) return;
   if (LW) column_unit_lw<U, R, NS>(L, cu);
@@ -39,6 +48,9 @@ void launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev) {
 }  // namespace
 
 void SS_INST_NAME(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev) {
+#ifdef SS_ONLY_NS   // experiment builds: a single stream count per unit
+  if (ns == SS_ONLY_NS) launch_ns<SS_ONLY_NS>(L, stream, ev);
+#else
   switch (ns) {
     case 1: launch_ns<1>(L, stream, ev); break;
     case 2: launch_ns<2>(L, stream, ev); break;
@@ -46,6 +58,7 @@ void SS_INST_NAME(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev) {
     case 8: launch_ns<8>(L, stream, ev); break;
     default: break;
   }
+#endif
 }
 
 }  // namespace ss

@@ -31,6 +31,8 @@
 #include "ss_common.hpp"
 #include "ss_layer_matrices.hpp"
 #include "ss_misc_units.hpp"
+#include "ss_column_lw.hpp"
+#include "ss_column_sw.hpp"
 #include "ss_solver_lw.hpp"
 #include "ss_solver_sw.hpp"
 
@@ -67,7 +69,8 @@ inline int lay_nelem(bool lw, const ClassKey& k) {
 }
 inline int col_nelem(bool lw, const ClassKey& k) {
   const int n = k.nreg * k.ns, d = k.nreg;
-  return lw ? 3 * n * n + 2 * n : 3 * n * n + 2 * n * d;
+  // LW: a_above + source_above; SW: a_above, d_above, LU(den), a_below, d_below
+  return lw ? n * n + n : 3 * n * n + 2 * n * d;
 }
 
 // Runtime (urban, nreg, ns) -> template instance

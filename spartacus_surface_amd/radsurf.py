@@ -20,8 +20,10 @@ import os
 
 from . import abi
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
-                         "libspartacus_surface_hip.so")
+# SPARTACUS_HIP_LIB selects another build of the SAME HIP library (kernel tuning
+# experiments under lib/variants/); it is never anything but a HIP build.
+_LIB_PATH = os.environ.get("SPARTACUS_HIP_LIB") or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), "lib", "libspartacus_surface_hip.so")
 _lib = None
 
 STATUS = {

@@ -90,6 +90,26 @@ def test_golden_plan_api_with_device_spectrum(name):
     plan.close()
 
 
+@pytest.mark.parametrize("name,nblock", [("simple__test_surfaces", None), ("urban__2stream", 16),
+                                         ("rami4pilps__vis-med-0.3", 7)])
+def test_fortran_shim_boundary(name, nblock):
+    """Reference derived types -> module radsurf_interface (ISO_C_BINDING shim,
+    spartacus_surface_amd/fortran) -> spartacus_radsurf_hip, driven like the
+    reference driver (OpenMP blocks of nblock columns, calc_simple_spectrum_lw
+    per block on the host)."""
+    from oracle import checker
+    _hip()
+    if not checker.have_shim():
+        pytest.skip("oracle/_ref/libspartacus_shim.so not built")
+    path = [p for p in golden_files() if os.path.basename(p)[:-4] == name][0]
+    case, expected = fixture_io.load_case(path)
+    out, _ = checker.run_shim(case["config"], case["canopy"], case["sw"], case["lw"],
+                              want_profiles=True, nblocksize=nblock,
+                              do_simple_spectrum=case["do_simple_spectrum"])
+    bad = fixture_io.parity_violations(fixture_io.flatten_outputs(out), expected, case["ref_noise"])
+    assert not bad, bad[:5]
+
+
 def test_column_range_slices_only():
     """Only (:, istartcol:iendcol) and the matching layer slices are written
     (radsurf_interface.F90:105; driver blocks, spartacus_surface_driver.F90:206-233)."""
@@ -134,26 +154,34 @@ def test_error_behaviour():
                         out["sw_norm_diff"], out["lw_internal"], out["lw_norm"])
 
 
-def _check_against_oracle(case, ncheck, tol=1.0e-7):
+def _check_against_oracle(case, ncheck):
+    """Solve the whole case on the GPU (plan API) and compare its first ncheck
+    columns with the CPU oracle under the parity bar; the reference's own
+    rounding error per variable is measured on the spot with the binary128
+    build of the oracle.  Returns (gpu outputs, [violations])."""
     from oracle import checker
+    from spartacus_surface_amd import workloads
     radsurf = _hip()
     cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
-    plan = radsurf.Plan(cfg, cp, sw, lw, want_profiles=case.get("want_profiles", False))
+    prof = case.get("want_profiles", False)
+    plan = radsurf.Plan(cfg, cp, sw, lw, want_profiles=prof)
     plan.solve()
-    out = checker.alloc_outputs(cfg, cp, case.get("want_profiles", False))
+    out = checker.alloc_outputs(cfg, cp, prof)
     plan.download(out["bc_out"], out["sw_norm_dir"], out["sw_norm_diff"], out["lw_internal"],
                   out["lw_norm"])
     assert plan.eigen_failures() == 0
     plan.close()
     got = fixture_io.flatten_outputs(out)
-    ref_out, _ = checker.run_oracle(cfg, cp, sw, lw, want_profiles=case.get("want_profiles", False),
-                                    istartcol=1, iendcol=ncheck, nthreads=8)
-    ref = fixture_io.flatten_outputs(ref_out)
-    nl = int(cp.istartlay[ncheck - 1] - 1 + cp.nlay[ncheck - 1])
+    head = workloads.head_columns(case, ncheck)
+    a = (head["config"], head["canopy"], head["sw"], head["lw"])
+    ref = fixture_io.flatten_outputs(checker.run_oracle(*a, want_profiles=prof, nthreads=8)[0])
+    truth = fixture_io.flatten_outputs(checker.run_oracle(*a, want_profiles=prof, nthreads=8,
+                                                          quad=True)[0])
+    noise = fixture_io.rel_errors(ref, truth)
+    nl = int(head["canopy"].ntotlay)
     sl = lambda a: a[:ncheck] if a.shape[0] == cp.ncol else a[:nl]   # noqa: E731
-    err, where = fixture_io.max_rel_error({k: sl(v) for k, v in got.items()},
-                                          {k: sl(v) for k, v in ref.items()})
-    return got, err, where
+    bad = fixture_io.parity_violations({k: sl(v) for k, v in got.items()}, ref, noise)
+    return got, bad
 
 
 def test_synthetic_c3_vs_oracle():
@@ -161,22 +189,22 @@ def test_synthetic_c3_vs_oracle():
     size the oracle finishes in seconds."""
     from spartacus_surface_amd import workloads
     case = workloads.c3_vegetated_urban(ncol=4096, seed=12345)
-    _, err, where = _check_against_oracle(case, 4096)
-    assert err <= fixture_io.PARITY_TOL, (err, where)
+    _, bad = _check_against_oracle(case, 4096)
+    assert not bad, bad[:5]
 
 
 def test_synthetic_c2_vs_oracle():
     from spartacus_surface_amd import workloads
     case = workloads.c2_rami4pilps(ncol=4600)
-    _, err, where = _check_against_oracle(case, 4600)
-    assert err <= fixture_io.PARITY_TOL, (err, where)
+    _, bad = _check_against_oracle(case, 4600)
+    assert not bad, bad[:5]
 
 
 def test_synthetic_c4_mixed_multiband_vs_oracle():
     from spartacus_surface_amd import workloads
     case = workloads.c4_mixed(ncol=512, seed=12345)
-    _, err, where = _check_against_oracle(case, 512)
-    assert err <= fixture_io.PARITY_TOL, (err, where)
+    _, bad = _check_against_oracle(case, 512)
+    assert not bad, bad[:5]
 
 
 def test_full_size_properties_c3():
@@ -187,10 +215,10 @@ def test_full_size_properties_c3():
     (ground + air + walls + roofs + vegetation - top net ~ 0)."""
     from spartacus_surface_amd import workloads
     big = workloads.c3_vegetated_urban(ncol=1_000_000, seed=12345)
-    got_big, err, where = _check_against_oracle(big, 2048)
-    assert err <= fixture_io.PARITY_TOL, (err, where)
+    got_big, bad = _check_against_oracle(big, 2048)
+    assert not bad, bad[:5]
     small = workloads.head_columns(big, 2048)
-    got_small, err_s, _ = _check_against_oracle(small, 2048)
+    got_small, _ = _check_against_oracle(small, 2048)
     cp = small["canopy"]
     nl = int(cp.ntotlay)
     for k, v in got_small.items():
