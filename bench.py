@@ -76,6 +76,41 @@ def cpu_baseline(ncol_sample):
                          if kind == "reference" else "gcc -O2 OpenMP C port")}
 
 
+def measured_traffic(family, cols_per_launch):
+    """HBM bytes per launch of a kernel family from the committed PMC summary
+    (profiles/traffic.json, written by tools/pmc_to_profile.py from separate
+    rocprofv3 --pmc passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        return t["bytes_per_column"][family] * cols_per_launch, t.get("source")
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
+def host_entry_rate(ncol):
+    """PCIe-inclusive rate of the host entry point (spartacus_radsurf_hip: host
+    buffers in, host buffers out, one call for all columns) on a bounded sample.
+    Reported next to the headline value, never as the value."""
+    from spartacus_surface_amd import radsurf, workloads, types
+    case = workloads.c3_vegetated_urban(ncol=ncol, seed=999)
+    cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
+    bc = types.BoundaryCondsOut()
+    bc.allocate(cp.ncol, cfg.nsw, cfg.nlw)
+    fl = []
+    for nspec, direct in ((cfg.nsw, True), (cfg.nsw, False), (cfg.nlw, False), (cfg.nlw, False)):
+        f = types.CanopyFlux()
+        f.allocate(cfg, cp.ncol, cp.ntotlay, nspec, use_direct=direct, do_save_flux_profile=False)
+        fl.append(f)
+    best = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        radsurf.radsurf(cfg, cp, sw, lw, bc, 1, cp.ncol, *fl)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {"value": ncol / best, "unit": "columns/s", "sample": "%d columns, host buffers in/out" % ncol}
+
+
 class _DevArray:
     """CUDA-array-interface view of a device array owned by the plan."""
 
@@ -165,6 +200,7 @@ def main():
         avg_ms = fam_ms[dom] / max(1, fam_n[dom])
         cols_per_launch = args.columns * args.steps / max(1, fam_n[dom])
         achieved = bpc * cols_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(dom, cols_per_launch)
         fpc = flops_per_column(case)
         kernel_total_ms = sum(fam_ms.values()) / args.steps
         line = {
@@ -178,7 +214,8 @@ def main():
                        "columns_per_gpu": args.columns, "layers": 10, "nsw": cfg.nsw,
                        "nlw": cfg.nlw, "parallelism": "columns sharded, %d GPU(s)" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_column": bpc, "avg_launch_ms": avg_ms,
                          "launches_per_step": fam_n[dom] / args.steps,
                          "note": "intensity ~%.0f flop/B: the path is fp64-VALU bound, "
@@ -192,6 +229,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+            line["pcie_inclusive"] = host_entry_rate(min(args.columns, 200_000))
         print(json.dumps(line), flush=True)
     plan.close()
     if world > 1:

@@ -18,9 +18,9 @@ namespace ss {
 
 template <int N>
 struct LwColRec {
-  static constexpr int AAB = 0;             // a_above(l)       N x N
-  static constexpr int SAB = AAB + N * N;   // source_above(l)  N
-  static constexpr int NELEM = SAB + N;
+  static constexpr int AAB = 0;                       // a_above(l)       N x N
+  static constexpr int SAB = AAB + rec_even(N * N);   // source_above(l)  N
+  static constexpr int NELEM = SAB + rec_even(N);
 };
 
 // denominator LU, a_below(l+1), source_below(l+1) (canopy parts) of layer l
@@ -68,7 +68,7 @@ SS_HD void column_unit_lw(const Launch& L, int cu) {
   const int nspec = L.nspec;
   const int nlay = in.nlay[col];
   const int l0 = in.istartlay[col] - 1;
-  const long stride = L.ncu;
+  constexpr long stride = kRecStride;
   const long cidx = (long)jb + (long)nspec * col;
 
   // ---- section 4: adding method with sources ----
@@ -93,8 +93,8 @@ SS_HD void column_unit_lw(const Launch& L, int cu) {
   }
 
   for (int jlay = 0; jlay < nlay; ++jlay) {
-    const double* lrec = L.lay + ((long)jlay * LRec::NELEM) * stride + cu;
-    double* crec = L.col + ((long)jlay * CRec::NELEM) * stride + cu;
+    const double* lrec = L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu);
+    double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
     const int lay = l0 + jlay;
     const long sidx = (long)jb + (long)nspec * lay;
     double Abe[N * N], Sbe[N];
@@ -190,8 +190,8 @@ SS_HD void column_unit_lw(const Launch& L, int cu) {
   emiss_factor = 2.0 * emiss_factor;
 
   for (int jlay = nlay - 1; jlay >= 0; --jlay) {
-    const double* lrec = L.lay + ((long)jlay * LRec::NELEM) * stride + cu;
-    const double* crec = L.col + ((long)jlay * CRec::NELEM) * stride + cu;
+    const double* lrec = L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu);
+    const double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
     const int lay = l0 + jlay;
     const long sidx = (long)jb + (long)nspec * lay;
     LwLayerProps<URBAN, NREG> p;

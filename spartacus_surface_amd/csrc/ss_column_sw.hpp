@@ -24,12 +24,12 @@ namespace ss {
 // Adding-method record of one layer in the column scratch [layer][elem][cu]
 template <int N, int D>
 struct SwColRec {
-  static constexpr int AAB = 0;                 // a_above(l)        N x N
-  static constexpr int DAB = AAB + N * N;       // d_above(l)        N x D
-  static constexpr int DEN = DAB + N * D;       // lu(denominator(l)) N x N
-  static constexpr int ABE = DEN + N * N;       // a_below(l+1)      N x N (canopy part)
-  static constexpr int DBE = ABE + N * N;       // d_below(l+1)      N x D (canopy part)
-  static constexpr int NELEM = DBE + N * D;
+  static constexpr int AAB = 0;                           // a_above(l)        N x N
+  static constexpr int DAB = AAB + rec_even(N * N);       // d_above(l)        N x D
+  static constexpr int DEN = DAB + rec_even(N * D);       // lu(denominator(l)) N x N
+  static constexpr int ABE = DEN + rec_even(N * N);       // a_below(l+1)      N x N (canopy part)
+  static constexpr int DBE = ABE + rec_even(N * N);       // d_below(l+1)      N x D (canopy part)
+  static constexpr int NELEM = DBE + rec_even(N * D);
 };
 
 template <bool URBAN, int NREG, int NS>
@@ -46,7 +46,7 @@ SS_HD void column_unit_sw(const Launch& L, int cu) {
   const int nspec = L.nspec;
   const int nlay = in.nlay[col];
   const int l0 = in.istartlay[col] - 1;
-  const long stride = L.ncu;
+  constexpr long stride = kRecStride;
   const long cidx = (long)jb + (long)nspec * col;
 
   const double cos_in = in.cos_sza[col];
@@ -84,8 +84,8 @@ SS_HD void column_unit_sw(const Launch& L, int cu) {
   }
 
   for (int jlay = 0; jlay < nlay; ++jlay) {
-    const double* lrec = L.lay + ((long)jlay * LRec::NELEM) * stride + cu;
-    double* crec = L.col + ((long)jlay * CRec::NELEM) * stride + cu;
+    const double* lrec = L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu);
+    double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
     const long sidx = (long)jb + (long)nspec * (l0 + jlay);
     double Abe[N * N], Dbe[N * D];
     {
@@ -210,8 +210,8 @@ SS_HD void column_unit_sw(const Launch& L, int cu) {
     double gvd = 0.0;
 
     for (int jlay = nlay - 1; jlay >= 0; --jlay) {
-      const double* lrec = L.lay + ((long)jlay * LRec::NELEM) * stride + cu;
-      const double* crec = L.col + ((long)jlay * CRec::NELEM) * stride + cu;
+      const double* lrec = L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu);
+      const double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
       const int lay = l0 + jlay;
       const long sidx = (long)jb + (long)nspec * lay;
       const LayerGeom g = load_layer_geom<URBAN, NREG>(in, lay);
@@ -473,8 +473,8 @@ SS_HD void column_unit_sw(const Launch& L, int cu) {
     PUTC(fb, F_TOP_NET, 1.0 - top_albedo_diff);
 
     for (int jlay = nlay - 1; jlay >= 0; --jlay) {
-      const double* lrec = L.lay + ((long)jlay * LRec::NELEM) * stride + cu;
-      const double* crec = L.col + ((long)jlay * CRec::NELEM) * stride + cu;
+      const double* lrec = L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu);
+      const double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
       const int lay = l0 + jlay;
       const long sidx = (long)jb + (long)nspec * lay;
       const LayerGeom g = load_layer_geom<URBAN, NREG>(in, lay);

@@ -123,8 +123,8 @@ struct Launch {
   int nspec;             // spectral bands (nsw or nlw)
   int ncu;               // column units = ncols * nspec
   int maxlay;            // largest nlay in the chunk
-  double* lay;           // layer-matrix scratch  [layer][elem][cu]
-  double* col;           // adding-method scratch [layer][elem][cu]
+  double* lay;           // layer-matrix scratch  [tile][layer][elem pair][lane][2]
+  double* col;           // adding-method scratch, same tiling
   double* top1;          // bc_out: sw_albedo / lw_emissivity   (nspec, ncol)
   double* top2;          // bc_out: sw_albedo_dir / lw_emission (nspec, ncol)
   FluxDev flux_a;        // sw_norm_dir  / lw_internal

@@ -29,49 +29,106 @@
 
 namespace ss {
 
-// Element offsets inside one layer record of the scratch [layer][elem][cu]
+// Element offsets inside one layer record of the scratch.  Scratch layout:
+// [tile of 64 column-units][layer][element pair][lane][2]: everything one
+// wavefront reads or writes for its 64 units is one contiguous block (all of a
+// wave's accesses fall into a few DRAM/TLB pages instead of one page per
+// element), and elements 2p and 2p+1 of a unit are adjacent, so that every lane
+// moves 16 bytes per access (global_load/store_dwordx4).  Every block of a
+// record therefore starts at an even element.
+constexpr int rec_even(int n) { return (n + 1) & ~1; }
+
 template <int NF, int DF>
 struct SwRec {
-  static constexpr int R = 0;                    // ref_diff        NF x NF
-  static constexpr int T = R + NF * NF;          // trans_diff      NF x NF
-  static constexpr int SUP = T + NF * NF;        // ref_dir         NF x DF
-  static constexpr int SDN = SUP + NF * DF;      // trans_dir_diff  NF x DF
-  static constexpr int EDIR = SDN + NF * DF;     // trans_dir_dir   DF x DF
-  static constexpr int IDIR = EDIR + DF * DF;    // int_dir         DF x DF
-  static constexpr int IDIFF = IDIR + DF * DF;   // int_diff        NF x NF
-  static constexpr int IDD = IDIFF + NF * NF;    // int_dir_diff    NF x DF
-  static constexpr int NELEM = IDD + NF * DF;
+  static constexpr int R = 0;                              // ref_diff        NF x NF
+  static constexpr int T = R + rec_even(NF * NF);          // trans_diff      NF x NF
+  static constexpr int SUP = T + rec_even(NF * NF);        // ref_dir         NF x DF
+  static constexpr int SDN = SUP + rec_even(NF * DF);      // trans_dir_diff  NF x DF
+  static constexpr int EDIR = SDN + rec_even(NF * DF);     // trans_dir_dir   DF x DF
+  static constexpr int IDIR = EDIR + rec_even(DF * DF);    // int_dir         DF x DF
+  static constexpr int IDIFF = IDIR + rec_even(DF * DF);   // int_diff        NF x NF
+  static constexpr int IDD = IDIFF + rec_even(NF * NF);    // int_dir_diff    NF x DF
+  static constexpr int NELEM = IDD + rec_even(NF * DF);
 };
 
 template <int NF>
 struct LwRec {
-  static constexpr int R = 0;                    // ref       NF x NF
-  static constexpr int T = R + NF * NF;          // trans     NF x NF
-  static constexpr int IFLUX = T + NF * NF;      // int_flux_mat NF x NF
-  static constexpr int SRC = IFLUX + NF * NF;    // source_lay   NF
-  static constexpr int ISRC = SRC + NF;          // int_source   NF
-  static constexpr int NELEM = ISRC + NF;
+  static constexpr int R = 0;                              // ref       NF x NF
+  static constexpr int T = R + rec_even(NF * NF);          // trans     NF x NF
+  static constexpr int IFLUX = T + rec_even(NF * NF);      // int_flux_mat NF x NF
+  static constexpr int SRC = IFLUX + rec_even(NF * NF);    // source_lay   NF
+  static constexpr int ISRC = SRC + rec_even(NF);          // int_source   NF
+  static constexpr int NELEM = ISRC + rec_even(NF);
 };
 
-// Writer of one scratch record: element e of this unit lives at rec[e * stride]
+// 16-byte element pair of the scratch
+struct alignas(16) RecPair { double x, y; };
+
+// Lanes per scratch tile (= wavefront size) and the element stride inside a tile
+constexpr long kRecStride = 64;
+
+// Offset of the record of column-unit cu in layer slot jlay (records of nelem
+// elements, maxlay layer slots per tile); element e (even) lives at + e * kRecStride
+SS_HD long rec_base(int jlay, int maxlay, int nelem, int cu) {
+  const long tile = cu >> 6, lane = cu & 63;
+  return ((tile * maxlay + jlay) * nelem) * kRecStride + 2 * lane;
+}
+
+// NEL consecutive elements starting at the EVEN element "off" of a record
+template <int NEL>
+SS_HD void rec_load(const double* rec, long stride, int off, double* dst) {
+  SS_UNROLL_FULL
+  for (int k = 0; k < NEL; k += 2) {
+    const RecPair v = *reinterpret_cast<const RecPair*>(rec + (long)(off + k) * stride);
+    dst[k] = v.x;
+    if (k + 1 < NEL) dst[k + 1] = v.y;
+  }
+}
+template <int NEL>
+SS_HD void rec_store(double* rec, long stride, int off, const double* src) {
+  SS_UNROLL_FULL
+  for (int k = 0; k < NEL; k += 2) {
+    RecPair v;
+    v.x = src[k];
+    v.y = (k + 1 < NEL) ? src[k + 1] : 0.0;
+    *reinterpret_cast<RecPair*>(rec + (long)(off + k) * stride) = v;
+  }
+}
+
+// Writer of one scratch record (rec = scratch + rec_base(...))
 struct RecWriter {
   double* rec;
   long stride;
-  SS_HD void put(int e, double v) const { rec[(long)e * stride] = v; }
+  // elements e (even) and e+1
+  SS_HD void put2(int e, double v0, double v1) const {
+    RecPair v;
+    v.x = v0;
+    v.y = v1;
+    *reinterpret_cast<RecPair*>(rec + (long)e * stride) = v;
+  }
 };
 
 // Write an (RS x CS) block held in registers into the (RF x CF) matrix that
-// starts at element "off", at block position (I0, J0); everything else zero.
+// starts at the even element "off", at block position (I0, J0); everything else zero.
 template <int RF, int CF, int RS, int CS, int I0, int J0>
 SS_HD void put_embedded(const RecWriter& w, int off, const double* blk) {
-  SS_UNROLL_N(CF)
-  for (int j = 0; j < CF; ++j) {
-    SS_UNROLL_N(RF)
-    for (int i = 0; i < RF; ++i) {
-      const bool inside = (i >= I0) && (i < I0 + RS) && (j >= J0) && (j < J0 + CS);
-      w.put(off + i + j * RF, inside ? SS_E(blk, i - I0, j - J0, RS) : 0.0);
-    }
-  }
+  auto val = [&](int idx) -> double {
+    const int i = idx % RF, j = idx / RF;
+    const bool inside = (idx < RF * CF) && (i >= I0) && (i < I0 + RS) && (j >= J0) && (j < J0 + CS);
+    return inside ? SS_E(blk, i - I0, j - J0, RS) : 0.0;
+  };
+  SS_UNROLL_FULL
+  for (int e = 0; e < RF * CF; e += 2) w.put2(off + e, val(e), val(e + 1));
+}
+// Same for a vector of NF elements holding an N-vector at I0
+template <int NF, int N, int I0, typename F>
+SS_HD void put_embedded_vec(const RecWriter& w, int off, F&& elem) {
+  auto val = [&](int i) -> double {
+    const bool inside = (i < NF) && (i >= I0) && (i < I0 + N);
+    return inside ? elem(i - I0) : 0.0;
+  };
+  SS_UNROLL_FULL
+  for (int e = 0; e < NF; e += 2) w.put2(off + e, val(e), val(e + 1));
 }
 
 template <int N>
@@ -357,11 +414,7 @@ SS_HD int calc_matrices_lw(const double* g1, const double* g2, const double* b, 
     SS_UNROLL_NN(N)
     for (int k = 0; k < N * N; ++k) G2D[k] += df.G2[k];
     mat_vec<N, N>(G2D, cb, v);
-    SS_UNROLL_N(NF)
-    for (int i = 0; i < NF; ++i) {
-      const bool inside = (i >= I0) && (i < I0 + N);
-      w.put(Rec::SRC + i, inside ? v[i - I0] + igb[i - I0] : 0.0);
-    }
+    put_embedded_vec<NF, N, I0>(w, Rec::SRC, [&](int i) { return v[i] + igb[i]; });
   }
   // Section 5 (:211-227): integrated fluxes
   {
@@ -379,11 +432,7 @@ SS_HD int calc_matrices_lw(const double* g1, const double* g2, const double* b, 
     mat_mul<N, N, N>(GZ, CS, IF);
     put_embedded<NF, NF, N, N, I0, I0>(w, Rec::IFLUX, IF);
     mat_vec<N, N>(GZ, cb, v);
-    SS_UNROLL_N(NF)
-    for (int i = 0; i < NF; ++i) {
-      const bool inside = (i >= I0) && (i < I0 + N);
-      w.put(Rec::ISRC + i, inside ? 2.0 * (v[i - I0] + igb[i - I0] * dz) : 0.0);
-    }
+    put_embedded_vec<NF, N, I0>(w, Rec::ISRC, [&](int i) { return 2.0 * (v[i] + igb[i] * dz); });
   }
   return ierr;
 }

@@ -15,7 +15,9 @@
 // HBM layout.  Inputs and outputs are byte-for-byte mirrors of the host
 // (Fortran) arrays, (nspec, ncol) / (nspec, ntotlay) with the band index
 // fastest.  The per-layer matrices live in two scratch buffers
-// [layer][element][column-unit]; column-unit = (column of the chunk, band) with
+// [tile of 64 column-units][layer][element pair][lane][2] (one contiguous block
+// per wavefront, 16 bytes per lane and access, ss_layer_matrices.hpp);
+// column-unit = (column of the chunk, band) with
 // the band fastest.  A class is processed in chunks of columns so that the
 // scratch stays bounded (default 4 GiB, env SPARTACUS_SCRATCH_MB).
 #pragma once
@@ -65,12 +67,14 @@ inline bool key_supported(const ClassKey& k) {
 // Number of scratch elements per layer of a class
 inline int lay_nelem(bool lw, const ClassKey& k) {
   const int n = k.nreg * k.ns, d = k.nreg;
-  return lw ? 3 * n * n + 2 * n : 3 * n * n + 3 * n * d + 2 * d * d;
+  auto ev = [](int x) { return (x + 1) & ~1; };   // blocks start at even elements (16-byte pairs)
+  return lw ? 3 * ev(n * n) + 2 * ev(n) : 3 * ev(n * n) + 3 * ev(n * d) + 2 * ev(d * d);
 }
 inline int col_nelem(bool lw, const ClassKey& k) {
   const int n = k.nreg * k.ns, d = k.nreg;
   // LW: a_above + source_above; SW: a_above, d_above, LU(den), a_below, d_below
-  return lw ? n * n + n : 3 * n * n + 2 * n * d;
+  auto ev = [](int x) { return (x + 1) & ~1; };
+  return lw ? ev(n * n) + ev(n) : 3 * ev(n * n) + 2 * ev(n * d);
 }
 
 // Runtime (urban, nreg, ns) -> template instance
@@ -377,12 +381,11 @@ class Plan {
     size_t need_lay = 0, need_col = 0;
     auto account = [&](const std::vector<ColumnClass>& cls, bool lw, int nspec) {
       for (auto& c : cls) {
-        const size_t per_col = (size_t)nspec * c.maxlay * sizeof(double);
-        const size_t tot = per_col * (lay_nelem(lw, c.key) + col_nelem(lw, c.key));
-        size_t chunk = std::max<size_t>(1, scratch_budget_bytes / std::max<size_t>(1, tot));
-        chunk = std::min(chunk, c.cols.size());
-        need_lay = std::max(need_lay, chunk * per_col * lay_nelem(lw, c.key));
-        need_col = std::max(need_col, chunk * per_col * col_nelem(lw, c.key));
+        const size_t per_unit = (size_t)c.maxlay * sizeof(double);
+        const size_t chunk = chunk_columns(c, lw, nspec);
+        const size_t units = ((chunk * nspec + 63) / 64) * 64;     // whole tiles of 64 units
+        need_lay = std::max(need_lay, units * per_unit * lay_nelem(lw, c.key));
+        need_col = std::max(need_col, units * per_unit * col_nelem(lw, c.key));
       }
     };
     account(sw_classes, false, nsw);
@@ -390,6 +393,16 @@ class Plan {
     if (need_lay > lay_bytes) { if (d_lay) Backend::free(d_lay); d_lay = static_cast<double*>(Backend::alloc(need_lay)); lay_bytes = need_lay; }
     if (need_col > col_bytes) { if (d_col) Backend::free(d_col); d_col = static_cast<double*>(Backend::alloc(need_col)); col_bytes = need_col; }
     return SS_OK;
+  }
+
+  // Columns of class c solved per launch so that both scratch buffers stay
+  // within the budget
+  size_t chunk_columns(const ColumnClass& c, bool lw, int nspec) const {
+    const size_t per_col = (size_t)nspec * c.maxlay * sizeof(double)
+                           * (lay_nelem(lw, c.key) + col_nelem(lw, c.key));
+    size_t chunk = std::max<size_t>(1, scratch_budget_bytes / std::max<size_t>(1, per_col));
+    if (chunk >= 128) chunk -= chunk % 64;     // whole waves where possible
+    return std::max<size_t>(1, std::min(chunk, c.cols.size()));
   }
 
   // ---- building the launch descriptors ----
@@ -537,12 +550,7 @@ class Plan {
       for (const auto& c : classes) {
         int rc = check_inputs(c.key, lw != 0);
         if (rc) return rc;
-        const size_t per_col = (size_t)nspec * c.maxlay * sizeof(double)
-                               * (lay_nelem(lw != 0, c.key) + col_nelem(lw != 0, c.key));
-        size_t chunk = std::max<size_t>(1, scratch_budget_bytes / std::max<size_t>(1, per_col));
-        // keep chunks a multiple of the wave size where possible
-        if (chunk >= 128) chunk -= chunk % 64;
-        chunk = std::max<size_t>(1, std::min(chunk, c.cols.size()));
+        const size_t chunk = chunk_columns(c, lw != 0, nspec);
         for (size_t first = 0; first < c.cols.size(); first += chunk) {
           const size_t count = std::min(chunk, c.cols.size() - first);
           const int chunk_maxlay = h_nlay[c.cols[first]];   // sorted descending

@@ -141,7 +141,7 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay) {
     }
   }
 
-  RecWriter w{L.lay + ((long)jlay * Rec::NELEM) * L.ncu + cu, (long)L.ncu};
+  RecWriter w{L.lay + rec_base(jlay, L.maxlay, Rec::NELEM, cu), kRecStride};
   int ierr;
   if (NREG == 1 || p.g.veg_fraction <= L.cfg.min_vegetation_fraction) {
     double s1[NS * NS], s2[NS * NS];

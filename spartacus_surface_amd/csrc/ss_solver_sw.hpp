@@ -21,17 +21,6 @@
 
 namespace ss {
 
-template <int NEL>
-SS_HD void rec_load(const double* rec, long stride, int off, double* dst) {
-  SS_UNROLL_FULL
-  for (int k = 0; k < NEL; ++k) dst[k] = rec[(long)(off + k) * stride];
-}
-template <int NEL>
-SS_HD void rec_store(double* rec, long stride, int off, const double* src) {
-  SS_UNROLL_FULL
-  for (int k = 0; k < NEL; ++k) rec[(long)(off + k) * stride] = src[k];
-}
-
 // Copy the (RS x CS) sub-block at (I0, J0) of an (RF x CF) matrix
 template <int RF, int RS, int CS, int I0, int J0>
 SS_HD void get_block(const double* A, double* B) {
@@ -175,7 +164,7 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay) {
   }
 
   // ---- layer matrices, 3-way branch (forest :408-455, urban :520-583) ----
-  RecWriter w{L.lay + ((long)jlay * Rec::NELEM) * L.ncu + cu, (long)L.ncu};
+  RecWriter w{L.lay + rec_base(jlay, L.maxlay, Rec::NELEM, cu), kRecStride};
   int ierr;
   if (NREG == 1 || g.veg_fraction <= L.cfg.min_vegetation_fraction) {
     // clear-sky region only: (1:ns, 1:1)

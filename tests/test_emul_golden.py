@@ -1,0 +1,54 @@
+"""CPU coverage of the kernel bodies and of the host-side plan logic.
+
+tests/emul/ss_emul.cpp compiles the SAME kernel headers (spartacus_surface_amd/
+csrc/*.hpp) and the same plan (ss_plan_impl.hpp: column classification, chunking,
+scratch layout, launch geometry) with g++ behind a backend that runs every
+"lane" as a plain function call.  This is TEST infrastructure (it is never
+loaded by the product path, which fails loudly without the HIP library); it
+lets the -m "not gpu" suite check the arithmetic and the indexing of the
+device code against the reference's golden vectors before a GPU is involved.
+"""
+import os
+
+import pytest
+
+from tests import fixture_io
+from tests.conftest import golden_files
+from tests.test_hip_parity import REFERENCE_SINGULAR
+
+# one case per code path, kept small so the CPU suite stays within minutes
+CASES = ["simple__test_surfaces", "simple__test_surfaces_1stream", "simple__test_empty_layers",
+         "simple__test_nearly_empty_layers", "simple__test_overhang", "simple__test_noscat",
+         "simple__test_closed", "single_layer__sp", "urban__1stream", "urban__2stream",
+         "urban__4stream", "urban__single", "rami4pilps__vis-med-0.3", "rami4pilps__vis-snw-0.3-2-4",
+         "rami5__HET07_JPS_SUM-56-direct"]
+
+
+def _available():
+    have = {os.path.basename(p)[:-4]: p for p in golden_files()}
+    return [have[c] for c in CASES if c in have] or list(have.values())[:4]
+
+
+@pytest.fixture(scope="module")
+def emul():
+    from tests import emul as e
+    e.build()
+    return e
+
+
+@pytest.mark.parametrize("path", _available(), ids=lambda p: os.path.basename(p)[:-4])
+def test_emulated_kernels_vs_golden(emul, path):
+    name = os.path.basename(path)[:-4]
+    case, expected = fixture_io.load_case(path)
+    cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
+    out, nfail = emul.run_emul(cfg, cp, sw, lw, want_profiles=case["want_profiles"],
+                               do_simple_spectrum=case["do_simple_spectrum"])
+    assert nfail == 0
+    got = fixture_io.flatten_outputs(out)
+    noise = dict(case["ref_noise"])
+    if name in REFERENCE_SINGULAR:
+        lim, bar = REFERENCE_SINGULAR[name]
+        expected = {k: v for k, v in expected.items() if noise.get(k, 0.0) <= lim}
+        noise = {k: bar / fixture_io.NOISE_FACTOR for k in noise}
+    bad = fixture_io.parity_violations(got, expected, noise)
+    assert not bad, "outside the parity bar: %s" % bad[:5]

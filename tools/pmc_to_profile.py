@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 --pmc passes of tools/profile_round.sh into
+profiles/<tag>_pmc.json (per kernel: registers, scratch, counters, derived
+per-column HBM traffic and executed fp64 flops) and refresh profiles/traffic.json,
+which bench.py reads to fill roofline.traffic.
+
+usage: tools/pmc_to_profile.py TAG NCOLUMNS   (NCOLUMNS = columns of the PMC runs)
+"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+tag, ncol = sys.argv[1], int(sys.argv[2])
+FAMILY = {("k_layer", "false"): "sw_layer", ("k_column", "false"): "sw_column",
+          ("k_down", "false"): "sw_down", ("k_down", "true"): "lw_down",
+          ("k_layer", "true"): "lw_layer", ("k_column", "true"): "lw_column"}
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+meta = {}
+for f in glob.glob("gpurun_out/pmc_%s/p*/*/*_counter_collection.csv" % tag):
+    for r in csv.DictReader(open(f)):
+        m = re.search(r"(k_\w+)<([^>]+)>", r["Kernel_Name"])
+        if not m:
+            continue
+        k = "%s<%s>" % (m.group(1), m.group(2))
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        meta[k] = {"vgpr": int(r["VGPR_Count"]), "agpr": int(r["Accum_VGPR_Count"]),
+                   "sgpr": int(r["SGPR_Count"]), "scratch_bytes_per_lane": int(r["Scratch_Size"]),
+                   "family": FAMILY.get((m.group(1), m.group(2).split(",")[-1].strip()), m.group(1))}
+out = {"command": "rocprofv3 --pmc <one group per pass> -- python bench.py --steps 1 --warmup 0 "
+                  "--columns %d --no-cpu-baseline (tools/profile_round.sh)" % ncol,
+       "columns": ncol, "kernels": {}}
+traffic = {}
+for k, c in sorted(agg.items()):
+    d = dict(meta[k])
+    d["counters"] = dict(c)
+    waves = max(1.0, c.get("SQ_WAVES", 1.0))
+    # FETCH_SIZE / WRITE_SIZE are in KiB-like units of 1024 B?  rocprofiler-sdk derives them as
+    # (requests * bytes) / 1024; see MI355X_MICROARCH.md "HBM": FETCH_SIZE counts 128-B requests
+    # of 16-B/lane reads at 64 B, so reads are doubled before being compared with a byte count.
+    fetch = c.get("FETCH_SIZE", 0.0) * 1024.0
+    write = c.get("WRITE_SIZE", 0.0) * 1024.0
+    d["derived"] = {
+        "fetch_bytes_per_column_raw": fetch / ncol, "fetch_bytes_per_column_x2": 2 * fetch / ncol,
+        "write_bytes_per_column": write / ncol,
+        "valu_insts_per_wave": c.get("SQ_INSTS_VALU", 0.0) / waves,
+        "wait_any_frac": c.get("SQ_WAIT_ANY", 0.0) / max(1.0, c.get("SQ_WAVE_CYCLES", 1.0)),
+        "active_frac": c.get("SQ_ACTIVE_INST_ANY", 0.0) / max(1.0, c.get("SQ_WAVE_CYCLES", 1.0)),
+    }
+    if "SQ_INSTS_VALU_FMA_F64" in c:
+        fl = 64.0 * (2 * c["SQ_INSTS_VALU_FMA_F64"] + c.get("SQ_INSTS_VALU_ADD_F64", 0.0)
+                     + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) + c.get("SQ_INSTS_VALU_TRANS_F64", 0.0))
+        d["derived"]["fp64_flops_per_column_executed"] = fl / ncol
+    out["kernels"][k] = d
+    fam = d["family"]
+    t = traffic.setdefault(fam, {"fetch_x2": 0.0, "write": 0.0, "flops": 0.0})
+    t["fetch_x2"] += 2 * fetch / ncol
+    t["write"] += write / ncol
+    t["flops"] += d["derived"].get("fp64_flops_per_column_executed", 0.0)
+json.dump(out, open("profiles/%s_pmc.json" % tag, "w"), indent=1)
+json.dump({"source": "profiles/%s_pmc.json" % tag, "workload": "C3, %d columns" % ncol,
+           "note": "HBM bytes per column per kernel family from FETCH_SIZE (x2, gfx950 correction of "
+                   "MI355X_MICROARCH.md) + WRITE_SIZE; separate --pmc passes",
+           "bytes_per_column": {f: t["fetch_x2"] + t["write"] for f, t in traffic.items()},
+           "fp64_flops_per_column_executed": {f: t["flops"] for f, t in traffic.items()}},
+          open("profiles/traffic.json", "w"), indent=1)
+print(json.dumps(json.load(open("profiles/traffic.json")), indent=1))
