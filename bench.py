@@ -172,7 +172,7 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    fam_ms = {k: 0.0 for k in ("sw_layer", "sw_column", "lw_layer", "lw_column")}
+    fam_ms = {k: 0.0 for k in ("sw_layer", "sw_column", "sw_down", "lw_layer", "lw_column", "lw_down")}
     fam_n = dict.fromkeys(fam_ms, 0)
     for _ in range(args.steps):
         step()

@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) k_spectrum_lay(const ss::SpectrumLaunch S
   if (i < S.nlays) ss::spectrum_lay_unit(S, i);
 }
 
-enum Family { FAM_SW_LAYER = 0, FAM_SW_COLUMN, FAM_LW_LAYER, FAM_LW_COLUMN, FAM_MISC, FAM_COUNT };
+enum Family { FAM_SW_LAYER = 0, FAM_SW_COLUMN, FAM_LW_LAYER, FAM_LW_COLUMN, FAM_MISC, FAM_SW_DOWN, FAM_LW_DOWN, FAM_COUNT };
 
 struct HipBackend {
   // HIP-event timing of every launch of the last solve, on the plan's stream
@@ -173,10 +173,11 @@ struct HipBackend {
       if (!key.urban) fn = key.nreg == 2 ? ss::launch_lw_forest_r2 : ss::launch_lw_forest_r3;
       else fn = key.nreg == 1 ? ss::launch_lw_urban_r1 : key.nreg == 2 ? ss::launch_lw_urban_r2 : ss::launch_lw_urban_r3;
     }
-    hipEvent_t ev[3] = {t.next(), t.next(), t.next()};
+    hipEvent_t ev[4] = {t.next(), t.next(), t.next(), t.next()};
     fn(key.ns, L, stream(), ev);
     t.spans.push_back({lw ? FAM_LW_LAYER : FAM_SW_LAYER, ev[0], ev[1]});
     t.spans.push_back({lw ? FAM_LW_COLUMN : FAM_SW_COLUMN, ev[1], ev[2]});
+    t.spans.push_back({lw ? FAM_LW_DOWN : FAM_SW_DOWN, ev[2], ev[3]});
     HIP_CHECK_THROW(hipGetLastError());
   }
 };
@@ -301,6 +302,8 @@ int ss_plan_last_kernel_ms(ss_plan* plan, const char* name, double* ms) {
     else if (fam == "sw_column") f = FAM_SW_COLUMN;
     else if (fam == "lw_layer") f = FAM_LW_LAYER;
     else if (fam == "lw_column") f = FAM_LW_COLUMN;
+    else if (fam == "sw_down") f = FAM_SW_DOWN;
+    else if (fam == "lw_down") f = FAM_LW_DOWN;
     else if (fam == "misc") f = FAM_MISC;
     if (f < 0) { g_last_error = "unknown kernel family"; return (int)SS_ERR_BAD_ARGUMENT; }
     double s = 0.0;

@@ -35,6 +35,15 @@
 #define SS_UNROLL_NN(N) SS_PRAGMA(unroll((N) <= SS_UNROLL_MAX ? (N) * (N) : 1))
 #define SS_UNROLL_FULL SS_PRAGMA(unroll)
 
+// Compiler-level fence that keeps the memory accesses written before it before
+// it in the instruction stream (no hardware wait): used to issue a whole group
+// of loads ahead of the arithmetic that overlaps with their latency.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SS_LOAD_FENCE() asm volatile("" ::: "memory")
+#else
+#define SS_LOAD_FENCE() do {} while (0)
+#endif
+
 namespace ss {
 
 constexpr double kPi = 3.14159265358979323846;   // radtool/radiation_constants.F90:24

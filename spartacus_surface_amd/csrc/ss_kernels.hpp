@@ -14,9 +14,9 @@ namespace ss {
 constexpr int kBlock = 64;   // one wavefront per workgroup: no LDS sharing, no barriers
 
 // Implemented once per (urban, nreg) in inst_*.hip; ns selects the instance.
-// Launches the layer kernel over (ncu x maxlay) units, then the column kernel
-// over ncu units, on "stream"; ev[0..2] (optional) are recorded before the
-// layer kernel, between the two kernels and after the column kernel.
+// Launches the layer kernel over (ncu x maxlay) units, then the upward and the
+// downward column kernels over ncu units, on "stream"; ev[0..3] (optional) are
+// recorded before, between and after the three kernels.
 using SolverLauncher = void (*)(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev);
 
 #define SS_DECL_LAUNCHER(name) void name(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev)

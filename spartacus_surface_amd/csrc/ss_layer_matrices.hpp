@@ -140,6 +140,16 @@ SS_HD void scale_cols(const double* A, const double* v, double* B) {
   }
 }
 
+// B = diag(v) A  (A is R x C)
+template <int R, int C>
+SS_HD void scale_rows(const double* A, const double* v, double* B) {
+  SS_UNROLL_FULL
+  for (int j = 0; j < C; ++j) {
+    SS_UNROLL_FULL
+    for (int i = 0; i < R; ++i) SS_E(B, i, j, R) = v[i] * SS_E(A, i, j, R);
+  }
+}
+
 // Diffuse part shared by SW and LW (sw_eig :180-221, lw_eig :142-176).
 // On return: G1, G2 = eigenvector blocks, lam, e = exp(-lam dz),
 // LUG1 = lu_factor(G1), Clo = C'_lower, Cup = C'_upper; R and T are written.
@@ -182,31 +192,34 @@ SS_HD int diffuse_part(const double* g1, const double* g2, double dz, Diffuse<N>
       SS_E(w.G2, i, j, N) = SS_E(X, i, j, N) - t;
     }
   }
-  // Eq. 48 by Schur complement
+  // Eq. 48 by Schur complement.  G1D = G1 diag(e) and G2D = G2 diag(e) are never
+  // formed: the scaling is applied to the rows of the right-hand factor.
   mat_copy<N, N>(w.G1, w.LUG1);
   lu_factor<N>(w.LUG1);
   {
-    double G2D[N * N], t1[N * N];
-    scale_cols<N>(w.G2, w.e, G2D);
-    mat_copy<N, N>(G2D, t1);
-    lu_solve_mat<N, N>(w.LUG1, t1);            // G1^-1 G2D
-    mat_mul<N, N, N>(G2D, t1, P);               // G2D G1^-1 G2D
+    double t1[N * N];
+    mat_copy<N, N>(w.G2, t1);
+    lu_solve_mat<N, N>(w.LUG1, t1);             // G1^-1 G2
+    SS_UNROLL_N(N)
+    for (int j = 0; j < N; ++j) {
+      SS_UNROLL_N(N)
+      for (int i = 0; i < N; ++i) SS_E(t1, i, j, N) *= w.e[i] * w.e[j];   // diag(e) G1^-1 G2 diag(e)
+    }
+    mat_mul<N, N, N>(w.G2, t1, P);               // G2D G1^-1 G2D
     SS_UNROLL_NN(N)
     for (int k = 0; k < N * N; ++k) P[k] = w.G1[k] - P[k];
     lu_factor<N>(P);
-    lu_invert<N>(P, w.Clo);                     // C'_lower = S^-1
-    mat_mul<N, N, N>(G2D, w.Clo, w.Cup);
+    lu_invert<N>(P, w.Clo);                      // C'_lower = S^-1
+    mat_mul_rs<N, N, N, false>(w.G2, w.e, w.Clo, w.Cup);    // G2D Clo
     lu_solve_mat<N, N>(w.LUG1, w.Cup);
     SS_UNROLL_NN(N)
     for (int k = 0; k < N * N; ++k) w.Cup[k] = -w.Cup[k];   // C'_upper
     // Eq. 49: R = G1D Cup + G2 Clo ; T = G2 Cup + G1D Clo
-    double G1D[N * N];
-    scale_cols<N>(w.G1, w.e, G1D);
-    mat_mul<N, N, N>(G1D, w.Cup, t1);
-    mat_mul_acc<N, N, N>(w.G2, w.Clo, t1);
+    mat_mul<N, N, N>(w.G2, w.Clo, t1);
+    mat_mul_rs<N, N, N, true>(w.G1, w.e, w.Cup, t1);
     putR(t1);
     mat_mul<N, N, N>(w.G2, w.Cup, t1);
-    mat_mul_acc<N, N, N>(G1D, w.Clo, t1);
+    mat_mul_rs<N, N, N, true>(w.G1, w.e, w.Clo, t1);
     putT(t1);
   }
   return ierr;
@@ -221,6 +234,44 @@ SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
   int ierr = 0;
   double mu[D], G0[D * D], G0inv[D * D], emu[D];
   double g3v[N * D], g4v[N * D];   // particular solutions, one column per direct eigenvalue
+
+  // schur_invert_sw (radtool_schur.F90:45-51) -> int_dir, int_diff, int_dir_diff
+  {
+    double g0i[D * D];
+    {
+      double LU0[D * D];
+      mat_copy<D, D>(g0, LU0);
+      lu_factor<D>(LU0);
+      lu_invert<D>(LU0, g0i);
+      double idir[D * D];
+      SS_UNROLL_FULL
+      for (int k = 0; k < D * D; ++k) idir[k] = -g0i[k];
+      put_embedded<DF, DF, D, D, R0, R0>(w, Rec::IDIR, idir);
+    }
+    double LU1[N * N], g1i[N * N], g2i[N * N], t[N * N];
+    mat_copy<N, N>(g1, LU1);
+    lu_factor<N>(LU1);
+    mat_copy<N, N>(g2, t);
+    lu_solve_mat<N, N>(LU1, t);                 // g1^-1 g2
+    mat_mul<N, N, N>(g2, t, g2i);
+    SS_UNROLL_NN(N)
+    for (int k = 0; k < N * N; ++k) g2i[k] = g1[k] - g2i[k];
+    lu_factor<N>(g2i);
+    lu_invert<N>(g2i, g1i);                     // g1i = (g1 - g2 g1^-1 g2)^-1
+    lu_invert<N>(LU1, t);                       // g1^-1
+    mat_mul<N, N, N>(g2, t, LU1);               // g2 g1^-1
+    mat_mul<N, N, N>(g1i, LU1, g2i);            // g2i
+    SS_UNROLL_NN(N)
+    for (int k = 0; k < N * N; ++k) t[k] = g2i[k] - g1i[k];
+    put_embedded<NF, NF, N, N, I0, I0>(w, Rec::IDIFF, t);      // int_diff = g2i - g1i
+    // g3i = (g1i - g2i) (g3 g0i);  int_dir_diff = 2 g3i = -2 t (g3 g0i)
+    double u[N * D], v[N * D];
+    mat_mul<N, D, D>(g3, g0i, u);
+    mat_mul<N, N, D>(t, u, v);
+    SS_UNROLL_FULL
+    for (int k = 0; k < N * D; ++k) v[k] = -2.0 * v[k];
+    put_embedded<NF, DF, N, D, I0, R0>(w, Rec::IDD, v);
+  }
 
   // Section 3 (:223-229): E = G0 diag(exp(mu dz)) G0^-1
   ierr += eigen_decomposition_real<D>(g0, mu, G0);
@@ -292,29 +343,30 @@ SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
       mat_mul<N, D, D>(g3e, G0inv, b1);    // = -(rhs of block 1)
       mat_mul<N, D, D>(g4v, G0inv, b2);    // = -(rhs of block 2)
     }
-    double G2D[N * N];
-    scale_cols<N>(df.G2, df.e, G2D);
-    // c2 = S^-1 (-b2 + G2D G1^-1 b1)
+    // c2 = S^-1 (-b2 + G2D G1^-1 b1)   (G2D x = G2 (diag(e) x))
+    double te[N * D];
     mat_copy<N, D>(b1, t);
     lu_solve_mat<N, D>(df.LUG1, t);
-    mat_mul<N, N, D>(G2D, t, c1);
+    scale_rows<N, D>(t, df.e, te);
+    mat_mul<N, N, D>(df.G2, te, c1);
     SS_UNROLL_FULL
     for (int k = 0; k < N * D; ++k) c1[k] = c1[k] - b2[k];
     mat_mul<N, N, D>(df.Clo, c1, c2);
     // c1 = G1^-1 (-b1 - G2D c2)
-    mat_mul<N, N, D>(G2D, c2, c1);
+    scale_rows<N, D>(c2, df.e, te);              // diag(e) c2, reused for S_dn
+    mat_mul<N, N, D>(df.G2, te, c1);
     SS_UNROLL_FULL
     for (int k = 0; k < N * D; ++k) c1[k] = -b1[k] - c1[k];
     lu_solve_mat<N, D>(df.LUG1, c1);
     // S_up = G1D c1 + G2 c2 + g3 G0^-1 ; S_dn = G2 c1 + G1D c2 + (g4 e) G0^-1
-    double G1D[N * N];
-    scale_cols<N>(df.G1, df.e, G1D);
-    mat_mul<N, N, D>(G1D, c1, t);
-    mat_mul_acc<N, N, D>(df.G2, c2, t);
-    mat_mul_acc<N, D, D>(g3v, G0inv, t);
-    put_embedded<NF, DF, N, D, I0, R0>(w, Rec::SUP, t);
     mat_mul<N, N, D>(df.G2, c1, t);
-    mat_mul_acc<N, N, D>(G1D, c2, t);
+    mat_mul_acc<N, N, D>(df.G1, te, t);          // S_dn without the particular part
+    scale_rows<N, D>(c1, df.e, te);              // diag(e) c1
+    double su[N * D];
+    mat_mul<N, N, D>(df.G1, te, su);
+    mat_mul_acc<N, N, D>(df.G2, c2, su);
+    mat_mul_acc<N, D, D>(g3v, G0inv, su);
+    put_embedded<NF, DF, N, D, I0, R0>(w, Rec::SUP, su);
     {
       double g4e[N * D];
       SS_UNROLL_N(D)
@@ -327,43 +379,6 @@ SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
     put_embedded<NF, DF, N, D, I0, R0>(w, Rec::SDN, t);
   }
 
-  // schur_invert_sw (radtool_schur.F90:45-51) -> int_dir, int_diff, int_dir_diff
-  {
-    double g0i[D * D];
-    {
-      double LU0[D * D];
-      mat_copy<D, D>(g0, LU0);
-      lu_factor<D>(LU0);
-      lu_invert<D>(LU0, g0i);
-      double idir[D * D];
-      SS_UNROLL_FULL
-      for (int k = 0; k < D * D; ++k) idir[k] = -g0i[k];
-      put_embedded<DF, DF, D, D, R0, R0>(w, Rec::IDIR, idir);
-    }
-    double LU1[N * N], g1i[N * N], g2i[N * N], t[N * N];
-    mat_copy<N, N>(g1, LU1);
-    lu_factor<N>(LU1);
-    mat_copy<N, N>(g2, t);
-    lu_solve_mat<N, N>(LU1, t);                 // g1^-1 g2
-    mat_mul<N, N, N>(g2, t, g2i);
-    SS_UNROLL_NN(N)
-    for (int k = 0; k < N * N; ++k) g2i[k] = g1[k] - g2i[k];
-    lu_factor<N>(g2i);
-    lu_invert<N>(g2i, g1i);                     // g1i = (g1 - g2 g1^-1 g2)^-1
-    lu_invert<N>(LU1, t);                       // g1^-1
-    mat_mul<N, N, N>(g2, t, LU1);               // g2 g1^-1
-    mat_mul<N, N, N>(g1i, LU1, g2i);            // g2i
-    SS_UNROLL_NN(N)
-    for (int k = 0; k < N * N; ++k) t[k] = g2i[k] - g1i[k];
-    put_embedded<NF, NF, N, N, I0, I0>(w, Rec::IDIFF, t);      // int_diff = g2i - g1i
-    // g3i = (g1i - g2i) (g3 g0i);  int_dir_diff = 2 g3i = -2 t (g3 g0i)
-    double u[N * D], v[N * D];
-    mat_mul<N, D, D>(g3, g0i, u);
-    mat_mul<N, N, D>(t, u, v);
-    SS_UNROLL_FULL
-    for (int k = 0; k < N * D; ++k) v[k] = -2.0 * v[k];
-    put_embedded<NF, DF, N, D, I0, R0>(w, Rec::IDD, v);
-  }
   return ierr;
 }
 
@@ -372,13 +387,7 @@ template <int NF, int N, int I0>
 SS_HD int calc_matrices_lw(const double* g1, const double* g2, const double* b, double dz,
                            const RecWriter& w) {
   using Rec = LwRec<NF>;
-  Diffuse<N> df;
-  int ierr = diffuse_part<N>(
-      g1, g2, dz, df,
-      [&](const double* R) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::R, R); },
-      [&](const double* T) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::T, T); });
-
-  // Section 3 (:178-195): inv_gamma_b
+  // Section 3 (:178-195): inv_gamma_b (first, while only the Gamma matrices are live)
   double igb[N];
   {
     double LU1[N * N], K[N * N], M[N * N];
@@ -395,25 +404,32 @@ SS_HD int calc_matrices_lw(const double* g1, const double* g2, const double* b, 
     lu_factor<N>(M);
     lu_solve<N>(M, igb);
   }
+  Diffuse<N> df;
+  int ierr = diffuse_part<N>(
+      g1, g2, dz, df,
+      [&](const double* R) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::R, R); },
+      [&](const double* T) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::T, T); });
+
   // Section 4 (:198-209): cb' and the source
   double cb[N], v[N];
   {
     double t[N];
     vec_copy<N>(igb, t);
     lu_solve<N>(df.LUG1, t);                    // g1^-1 inv_gamma_b
-    double G2D[N * N];
-    scale_cols<N>(df.G2, df.e, G2D);
-    mat_vec<N, N>(G2D, t, v);
+    double te[N];
+    SS_UNROLL_N(N)
+    for (int i = 0; i < N; ++i) te[i] = df.e[i] * t[i];
+    mat_vec<N, N>(df.G2, te, v);                // G2D g1^-1 igb
     SS_UNROLL_N(N)
     for (int i = 0; i < N; ++i) v[i] = igb[i] - v[i];
     mat_vec<N, N>(df.Clo, v, cb);
     SS_UNROLL_N(N)
     for (int i = 0; i < N; ++i) cb[i] = -cb[i];
     // source = (G1D + G2) cb' + inv_gamma_b
-    scale_cols<N>(df.G1, df.e, G2D);
-    SS_UNROLL_NN(N)
-    for (int k = 0; k < N * N; ++k) G2D[k] += df.G2[k];
-    mat_vec<N, N>(G2D, cb, v);
+    SS_UNROLL_N(N)
+    for (int i = 0; i < N; ++i) te[i] = df.e[i] * cb[i];
+    mat_vec<N, N>(df.G2, cb, v);
+    mat_vec_acc<N, N>(df.G1, te, v);
     put_embedded_vec<NF, N, I0>(w, Rec::SRC, [&](int i) { return v[i] + igb[i]; });
   }
   // Section 5 (:211-227): integrated fluxes

@@ -32,6 +32,13 @@ SS_HD void vec_copy(const double* a, double* b) {
   SS_UNROLL_N(N)
   for (int i = 0; i < N; ++i) b[i] = a[i];
 }
+template <int N>
+SS_HD double vec_sum(const double* a) {
+  double s = 0.0;
+  SS_UNROLL_FULL
+  for (int i = 0; i < N; ++i) s += a[i];
+  return s;
+}
 
 template <int R, int C>
 SS_HD void mat_zero(double* A) {
@@ -76,6 +83,24 @@ SS_HD void mat_mul_acc(const double* A, const double* B, double* C) {
       double s = SS_E(C, i, j, M);
       SS_UNROLL_N(K)
       for (int k = 0; k < K; ++k) s += SS_E(A, i, k, M) * SS_E(B, k, j, K);
+      SS_E(C, i, j, M) = s;
+    }
+  }
+}
+
+// C (+)= A diag(e) B without forming A diag(e) or diag(e) B
+template <int M, int K, int N, bool ACC>
+SS_HD void mat_mul_rs(const double* A, const double* e, const double* B, double* C) {
+  SS_UNROLL_N(N)
+  for (int j = 0; j < N; ++j) {
+    double eb[K];
+    SS_UNROLL_N(K)
+    for (int k = 0; k < K; ++k) eb[k] = e[k] * SS_E(B, k, j, K);
+    SS_UNROLL_N(M)
+    for (int i = 0; i < M; ++i) {
+      double s = ACC ? SS_E(C, i, j, M) : 0.0;
+      SS_UNROLL_N(K)
+      for (int k = 0; k < K; ++k) s += SS_E(A, i, k, M) * eb[k];
       SS_E(C, i, j, M) = s;
     }
   }

@@ -201,50 +201,64 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay) {
 // Interface geometry above layer jlay (0-based; jlay = -1 is the ground):
 // U (NREG x DB), V (DB x NREG).
 template <bool URBAN, bool LW, int NREG>
-SS_HD void interface_overlap(const Launch& L, int col, int jl_lower, double* U, double* V) {
+SS_HD void interface_overlap_vals(double thr, bool upper_is_sky, double vf_up, double bf_up,
+                                  bool lower_is_ground, double vf_lo, double bf_lo, double* U, double* V) {
   constexpr int DB = URBAN ? NREG + 1 : NREG;
-  const Inputs& in = L.in;
-  const int nlay = in.nlay[col];
-  const int l0 = in.istartlay[col] - 1;
   double fu[NREG], fl[DB];
-  // upper layer (jl_lower + 1), or the free atmosphere
-  if (jl_lower + 1 >= nlay) {
+  // upper layer, or the free atmosphere
+  if (upper_is_sky) {
     fu[0] = 1.0;
     SS_UNROLL_FULL
     for (int r = 1; r < NREG; ++r) fu[r] = 0.0;
   } else {
-    const int lay = l0 + jl_lower + 1;
-    region_fractions<URBAN, LW, NREG>((NREG > 1) ? in.veg_fraction[lay] : 0.0,
-                                      URBAN ? in.building_fraction[lay] : 0.0, fu);
+    region_fractions<URBAN, LW, NREG>((NREG > 1) ? vf_up : 0.0, URBAN ? bf_up : 0.0, fu);
   }
   if (!URBAN) {
-    if (jl_lower < 0) {
+    if (lower_is_ground) {
       fl[0] = 1.0;
       SS_UNROLL_FULL
       for (int r = 1; r < NREG; ++r) fl[r] = 0.0;
     } else {
-      const int lay = l0 + jl_lower;
-      region_fractions<URBAN, LW, NREG>((NREG > 1) ? in.veg_fraction[lay] : 0.0, 0.0, fl);
+      region_fractions<URBAN, LW, NREG>((NREG > 1) ? vf_lo : 0.0, 0.0, fl);
     }
-    overlap_forest<NREG>(fu, fl, L.cfg.min_vegetation_fraction, U, V);
+    overlap_forest<NREG>(fu, fl, thr, U, V);
   } else {
-    if (jl_lower < 0) {
+    if (lower_is_ground) {
       // ground = one "roof" region the size of the non-building part of layer 1
       double s = 0.0;
       SS_UNROLL_FULL
       for (int r = 0; r < NREG; ++r) { fl[r] = 0.0; s += fu[r]; }
       fl[DB - 1] = s;
     } else {
-      const int lay = l0 + jl_lower;
       double flo[NREG], sum_up = 0.0;
-      region_fractions<URBAN, LW, NREG>((NREG > 1) ? in.veg_fraction[lay] : 0.0,
-                                        in.building_fraction[lay], flo);
+      region_fractions<URBAN, LW, NREG>((NREG > 1) ? vf_lo : 0.0, bf_lo, flo);
       SS_UNROLL_FULL
       for (int r = 0; r < NREG; ++r) sum_up += fu[r];
-      urban_frac_lower<NREG>(flo, sum_up, jl_lower + 1 >= nlay, fl);
+      urban_frac_lower<NREG>(flo, sum_up, upper_is_sky, fl);
     }
-    overlap_urban<NREG>(fu, fl, L.cfg.min_vegetation_fraction, U, V);
+    overlap_urban<NREG>(fu, fl, thr, U, V);
   }
+}
+
+// The same from the column's packed arrays: interface between layer jl_lower
+// (or the ground, -1) and layer jl_lower + 1 (or the free atmosphere)
+template <bool URBAN, bool LW, int NREG>
+SS_HD void interface_overlap(const Launch& L, int col, int jl_lower, double* U, double* V) {
+  const Inputs& in = L.in;
+  const int nlay = in.nlay[col];
+  const int l0 = in.istartlay[col] - 1;
+  const bool sky = jl_lower + 1 >= nlay, ground = jl_lower < 0;
+  double vf_up = 0.0, bf_up = 0.0, vf_lo = 0.0, bf_lo = 0.0;
+  if (!sky) {
+    if (NREG > 1) vf_up = in.veg_fraction[l0 + jl_lower + 1];
+    if (URBAN) bf_up = in.building_fraction[l0 + jl_lower + 1];
+  }
+  if (!ground) {
+    if (NREG > 1) vf_lo = in.veg_fraction[l0 + jl_lower];
+    if (URBAN) bf_lo = in.building_fraction[l0 + jl_lower];
+  }
+  interface_overlap_vals<URBAN, LW, NREG>(L.cfg.min_vegetation_fraction, sky, vf_up, bf_up, ground,
+                                          vf_lo, bf_lo, U, V);
 }
 
 // y (DB*NS) = (V (x) I) x (NREG*NS)      rect_expandedmat_x_vec :608
