@@ -53,7 +53,26 @@ def flops_per_column(case):
     return tot
 
 
-def cpu_baseline(ncol_sample):
+WORKLOAD_NAMES = {
+    "c2": "C2: test/rami4pilps forest SW (vis-med-0.3), 2 regions x 1 stream x 2 layers, 1 band",
+    "c3": "C3: test/urban vegetated-urban SW+LW, 3 regions x 2 streams x 10 layers, 1 SW + 1 LW band",
+    "c3ns4": "C3 with 4 streams: vegetated-urban SW+LW, 3 regions x 4 streams x 10 layers (n = 12)",
+    "c4": "C4: mixed forest / vegetated-urban SW+LW, 3 regions x 2 streams x 10 layers, 14 SW + 16 LW bands",
+}
+
+
+def make_case(workload, ncol, seed):
+    from spartacus_surface_amd import workloads
+    if workload == "c2":
+        return workloads.c2_rami4pilps(ncol=ncol)
+    if workload == "c3ns4":
+        return workloads.c3_vegetated_urban(ncol=ncol, seed=seed, nstream=4)
+    if workload == "c4":
+        return workloads.c4_mixed(ncol=ncol, seed=seed)
+    return workloads.c3_vegetated_urban(ncol=ncol, seed=seed)
+
+
+def cpu_baseline(workload, ncol_sample):
     """The REAL reference (oracle/_ref: Fortran compiled with flang -O2, OpenMP
     block loop of its driver, nblocksize 16, schedule dynamic) on a bounded
     sample of the same workload.  Falls back to the C port if _ref is absent."""
@@ -62,7 +81,7 @@ def cpu_baseline(ncol_sample):
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     os.environ.setdefault("OMP_SCHEDULE", "dynamic")
     from oracle import checker
-    case = workloads.c3_vegetated_urban(ncol=ncol_sample, seed=12345)
+    case = make_case(workload, ncol_sample, 12345)
     a = (case["config"], case["canopy"], case["sw"], case["lw"])
     if checker.have_ref():
         _, sec = checker.run_ref(*a, want_profiles=False, nblocksize=16, nrepeat=1)
@@ -71,15 +90,17 @@ def cpu_baseline(ncol_sample):
         _, sec = checker.run_oracle(*a, want_profiles=False, nthreads=cores)
         kind = "port"
     return {"value": ncol_sample / sec, "unit": "columns/s", "cores": cores, "kind": kind,
-            "sample": "%d columns of the bench workload (C3, SW+LW), %.1f s, %s"
-                      % (ncol_sample, sec, "flang -O2 OpenMP dynamic nblocksize=16"
+            "sample": "%d columns of the bench workload (%s), %.1f s, %s"
+                      % (ncol_sample, workload, sec, "flang -O2 OpenMP dynamic nblocksize=16"
                          if kind == "reference" else "gcc -O2 OpenMP C port")}
 
 
-def measured_traffic(family, cols_per_launch):
+def measured_traffic(family, cols_per_launch, workload="c3"):
     """HBM bytes per launch of a kernel family from the committed PMC summary
     (profiles/traffic.json, written by tools/pmc_to_profile.py from separate
     rocprofv3 --pmc passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)."""
+    if workload != "c3":
+        return None, None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
@@ -93,7 +114,7 @@ def host_entry_rate(ncol):
     buffers in, host buffers out, one call for all columns) on a bounded sample.
     Reported next to the headline value, never as the value."""
     from spartacus_surface_amd import radsurf, workloads, types
-    case = workloads.c3_vegetated_urban(ncol=ncol, seed=999)
+    case = make_case("c3", ncol, 999)
     cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
     bc = types.BoundaryCondsOut()
     bc.allocate(cp.ncol, cfg.nsw, cfg.nlw)
@@ -125,6 +146,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--columns", type=int, default=1_000_000, help="columns per GPU")
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3ns4", "c4"],
+                    help="c3 (default) is the headline configuration; the others are extra lines")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -145,7 +168,7 @@ def main():
     radsurf.load_library()
     radsurf.set_device(local_rank)
 
-    case = workloads.c3_vegetated_urban(ncol=args.columns, seed=12345 + rank)
+    case = make_case(args.workload, args.columns, 12345 + rank)
     cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
     plan = radsurf.Plan(cfg, cp, sw, lw, want_profiles=False)   # inputs now resident in HBM
 
@@ -200,7 +223,7 @@ def main():
         avg_ms = fam_ms[dom] / max(1, fam_n[dom])
         cols_per_launch = args.columns * args.steps / max(1, fam_n[dom])
         achieved = bpc * cols_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(dom, cols_per_launch)
+        traffic, traffic_src = measured_traffic(dom, cols_per_launch, args.workload)
         fpc = flops_per_column(case)
         kernel_total_ms = sum(fam_ms.values()) / args.steps
         line = {
@@ -208,10 +231,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C3: test/urban vegetated-urban SW+LW, 3 regions x 2 streams "
-                                   "x 10 layers, 1 SW + 1 LW band, %d columns per GPU, seed 12345"
-                                   % args.columns,
-                       "columns_per_gpu": args.columns, "layers": 10, "nsw": cfg.nsw,
+            "config": {"workload": "%s, %d columns per GPU, seed 12345"
+                                   % (WORKLOAD_NAMES[args.workload], args.columns),
+                       "columns_per_gpu": args.columns,
+                       "layers": float(cp.ntotlay) / max(1, cp.ncol), "nsw": cfg.nsw,
                        "nlw": cfg.nlw, "parallelism": "columns sharded, %d GPU(s)" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -228,7 +251,7 @@ def main():
             "eigen_failures": nfail,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample)
+            line["cpu_baseline"] = cpu_baseline(args.workload, min(args.cpu_sample, args.columns))
             line["pcie_inclusive"] = host_entry_rate(min(args.columns, 200_000))
         print(json.dumps(line), flush=True)
     plan.close()

@@ -1,11 +1,8 @@
 // ss_column_lw.hpp - longwave column unit: adding method with sources (forest
 // radsurf_forest_lw.F90:452-506, urban radsurf_urban_lw.F90:551-626) and the
 // internal-emission and incoming-flux passes (forest :508-694, urban :628-858)
-// of one (column, band), both passes in ONE downward sweep.  Only a_above(l),
-// source_above(l) are stored per layer; the sweep recomputes LU(denominator),
-// a_below and source_below from them and from the layer record it loads anyway
-// (bit-identical to the upward values) - measured 17.9 -> 13.6 ms per 1e6
-// columns on MI355X against storing them (profiles/round1_column_variants.md).
+// of one (column, band): k_up stores the adding-method matrices of every layer,
+// k_down runs the two passes on paired lanes (same structure as ss_column_sw.hpp).
 #pragma once
 
 #include "ss_common.hpp"
@@ -18,9 +15,13 @@ namespace ss {
 
 template <int N>
 struct LwColRec {
-  static constexpr int AAB = 0;                       // a_above(l)       N x N
-  static constexpr int SAB = AAB + rec_even(N * N);   // source_above(l)  N
-  static constexpr int NELEM = SAB + rec_even(N);
+  static constexpr int AAB = 0;                       // a_above(l)        N x N
+  static constexpr int DEN = AAB + rec_even(N * N);   // lu(denominator(l)) N x N
+  static constexpr int ABE = DEN + rec_even(N * N);   // a_below(l+1)      N x N (canopy part)
+  static constexpr int SAB = ABE + rec_even(N * N);   // source_above(l)   N
+  static constexpr int SBE = SAB + rec_even(N);       // source_below(l+1) N (canopy part)
+  static constexpr int RS = SBE + rec_even(N);        // R source_above + source_lay  N
+  static constexpr int NELEM = RS + rec_even(N);
 };
 
 // denominator LU, a_below(l+1), source_below(l+1) (canopy parts) of layer l
@@ -54,11 +55,11 @@ SS_HD void lw_adding_step(const double* Aab, const double* Sab, const double* R,
   }
 }
 
+// ---- section 4: adding method with sources, upward (k_up) ----
 template <bool URBAN, int NREG, int NS>
-SS_HD void column_unit_lw(const Launch& L, int cu) {
+SS_HD void column_up_lw(const Launch& L, int cu) {
   constexpr int N = NREG * NS;
   constexpr int DB = URBAN ? NREG + 1 : NREG;
-  constexpr int NB = DB * NS;
   using LRec = LwRec<N>;
   using CRec = LwColRec<N>;
   const Inputs& in = L.in;
@@ -71,7 +72,6 @@ SS_HD void column_unit_lw(const Launch& L, int cu) {
   constexpr long stride = kRecStride;
   const long cidx = (long)jb + (long)nspec * col;
 
-  // ---- section 4: adding method with sources ----
   double Aab[N * N], Sab[N];
   mat_zero<N, N>(Aab);
   {
@@ -106,6 +106,15 @@ SS_HD void column_unit_lw(const Launch& L, int cu) {
       rec_store<N * N>(crec, stride, CRec::AAB, Aab);
       rec_store<N>(crec, stride, CRec::SAB, Sab);
       lw_adding_step<N>(Aab, Sab, R, T, Sl, Den, Abe, Sbe);
+      rec_store<N * N>(crec, stride, CRec::DEN, Den);
+      rec_store<N * N>(crec, stride, CRec::ABE, Abe);
+      rec_store<N>(crec, stride, CRec::SBE, Sbe);
+      // term of the downward sweep that does not depend on the incoming flux
+      double rs[N];
+      mat_vec<N, N>(R, Sab, rs);
+      SS_UNROLL_N(N)
+      for (int i = 0; i < N; ++i) rs[i] = rs[i] + Sl[i];
+      rec_store<N>(crec, stride, CRec::RS, rs);
     }
     {
       double U[NREG * DB], V[DB * NREG];
@@ -147,7 +156,6 @@ SS_HD void column_unit_lw(const Launch& L, int cu) {
     }
   }
 
-  double top_emissivity, top_emission;
   {
     double s = 0.0;
     SS_UNROLL_FULL
@@ -157,282 +165,284 @@ SS_HD void column_unit_lw(const Launch& L, int cu) {
       for (int j2 = 0; j2 < NS; ++j2) acc += SS_E(Aab, j1, j2, N) * lg.hweight[j2];
       s += acc;
     }
-    top_emissivity = 1.0 - s;
+    L.top1[cidx] = 1.0 - s;           // top_emissivity
     s = 0.0;
     SS_UNROLL_FULL
     for (int j1 = 0; j1 < NS; ++j1) s += Sab[j1];
-    top_emission = s;
-    L.top1[cidx] = top_emissivity;
-    L.top2[cidx] = top_emission;
+    L.top2[cidx] = s;                 // top_emission
   }
+}
 
-  const FluxDev& fa = L.flux_a;   // lw_internal
-  const FluxDev& fb = L.flux_b;   // lw_norm
-#define PUTC(fd, F, v) do { if ((fd).f[F]) (fd).f[F][cidx] = (v); } while (0)
-#define PUTL(fd, F, v) do { if ((fd).f[F]) (fd).f[F][sidx] = (v); } while (0)
+// Value held by the partner lane (the other pass of the same column unit).  On
+// the host the two passes run one after the other and hand the value over
+// through "slot".
+SS_HD double lw_partner_value(double v, int pass, double* slot) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  (void)pass; (void)slot;
+  return __shfl_xor(v, 1);
+#else
+  if (pass == 0) { *slot = v; return 0.0; }
+  return *slot;
+#endif
+}
 
-  // ---- section 5: "a" = internal emission, "b" = incoming at canopy top ----
-  double dna_above[N], upa_above[N], dnb_above[N], upb_above[N];
-  vec_zero<N>(dna_above);
-  vec_zero<N>(upa_above);
-  vec_zero<N>(dnb_above);
-  vec_zero<N>(upb_above);
-  SS_UNROLL_FULL
-  for (int js = 0; js < NS; ++js) dnb_above[js] = lg.hweight[js];
-  PUTC(fa, F_TOP_DN, 0.0);
-  PUTC(fa, F_TOP_NET, -top_emission);
-  PUTC(fb, F_TOP_DN, 1.0);
-  PUTC(fb, F_TOP_NET, top_emissivity);
+// ---- section 5: downward sweep (k_down) ----
+// One lane = (column, band, pass): pass 0 = internal emission (lw_internal,
+// forest :508-610 / urban :628-752), pass 1 = incoming flux at canopy top
+// (lw_norm, forest :612-694 / urban :754-858).  Pass 1 is pass 0 with every
+// source switched off and a unit incoming flux, so both run one instruction
+// stream and share their memory requests; software-pipelined like the
+// shortwave sweep (ss_column_sw.hpp).
+template <bool URBAN, int NREG, int NS>
+SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
+  constexpr int N = NREG * NS;
+  constexpr int DB = URBAN ? NREG + 1 : NREG;
+  constexpr int NB = DB * NS;
+  using LRec = LwRec<N>;
+  using CRec = LwColRec<N>;
+  constexpr long st = kRecStride;
+  const Inputs& in = L.in;
+  const LG& lg = L.lg;
+  const int col = L.cols[cu / L.nspec];
+  const int jb = cu % L.nspec;
+  const int nspec = L.nspec;
+  const int nlay = in.nlay[col];
+  const int l0 = in.istartlay[col] - 1;
+  const long cidx = (long)jb + (long)nspec * col;
+  const bool internal = (pass == 0);
+  const double src = internal ? 1.0 : 0.0;     // switches the emission terms
+  const double top_emissivity = L.top1[cidx], top_emission = L.top2[cidx];
+
+#define FSEL(F) (internal ? L.flux_a.f[F] : L.flux_b.f[F])
+#define PUTC(F, v) do { double* p_ = FSEL(F); if (p_) p_[cidx] = (v); } while (0)
+#define PUTL(F, v) do { double* p_ = FSEL(F); if (p_) p_[sidx] = (v); } while (0)
+
+  double dn_above[N], up_above[N];
+  vec_zero<N>(dn_above);
+  vec_zero<N>(up_above);
+  if (!internal) {
+    SS_UNROLL_FULL
+    for (int js = 0; js < NS; ++js) dn_above[js] = lg.hweight[js];
+  }
+  PUTC(F_TOP_DN, internal ? 0.0 : 1.0);
+  PUTC(F_TOP_NET, internal ? -top_emission : top_emissivity);
 
   double emiss_factor = 0.0;
   SS_UNROLL_FULL
   for (int js = 0; js < NS; ++js) emiss_factor += lg.hweight[js] / lg.mu[js];
   emiss_factor = 2.0 * emiss_factor;
 
+  // group 1 of the top layer and its scalars; fractions of the layer above
+  LwLayerIn<URBAN, NREG> din;
+  double ABE[N * N], SBE[N];
+  double vf_up = 0.0, bf_up = 0.0;
+  if (nlay > 0) {
+    const int jlay = nlay - 1;
+    const double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
+    din.load(in, l0 + jlay, (long)jb + (long)nspec * (l0 + jlay));
+    rec_load<N * N>(crec, st, CRec::ABE, ABE);
+    rec_load<N>(crec, st, CRec::SBE, SBE);
+  }
+
   for (int jlay = nlay - 1; jlay >= 0; --jlay) {
     const double* lrec = L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu);
     const double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
     const int lay = l0 + jlay;
     const long sidx = (long)jb + (long)nspec * lay;
-    LwLayerProps<URBAN, NREG> p;
-    lw_layer_props<URBAN, NREG>(L, lay, sidx, p);
+    const LwLayerIn<URBAN, NREG> dcur = din;
+
+    // ---- issue group 2 (T, R source_above + source_lay), work on group 1 ----
+    double T[N * N], RS[N];
+    rec_load<N * N>(lrec, st, LRec::T, T);
+    rec_load<N>(crec, st, CRec::RS, RS);
+    SS_LOAD_FENCE();
+
     double U[NREG * DB], V[DB * NREG];
-    interface_overlap<URBAN, true, NREG>(L, col, jlay, U, V);
-
-    double dna_below[NB], dnb_below[NB], upa_below[NB], upb_below[NB];
-    apply_V_vec<NREG, DB, NS>(V, dna_above, dna_below);
-    apply_V_vec<NREG, DB, NS>(V, dnb_above, dnb_below);
-
-    // LU(denominator), a_below and source_below recomputed with the arithmetic
-    // of the upward sweep (bit-identical), see the header comment
-    double R[N * N], T[N * N], Den[N * N], AabL[N * N], Sl[N], SabL[N];
-    rec_load<N * N>(lrec, stride, LRec::R, R);
-    rec_load<N * N>(lrec, stride, LRec::T, T);
-    rec_load<N>(lrec, stride, LRec::SRC, Sl);
-    rec_load<N * N>(crec, stride, CRec::AAB, AabL);
-    rec_load<N>(crec, stride, CRec::SAB, SabL);
-    {
-      double Abe[N * N], Sbe[N];
-      lw_adding_step<N>(AabL, SabL, R, T, Sl, Den, Abe, Sbe);
-      mat_vec<N, N>(Abe, dna_below, upa_below);
-      SS_UNROLL_N(N)
-      for (int i = 0; i < N; ++i) upa_below[i] = upa_below[i] + Sbe[i];
-      mat_vec<N, N>(Abe, dnb_below, upb_below);
-    }
+    interface_overlap_vals<URBAN, true, NREG>(L.cfg.min_vegetation_fraction, jlay + 1 >= nlay, vf_up, bf_up,
+                                              false, dcur.g.veg_fraction, dcur.g.building_fraction, U, V);
+    double dn_below[NB], up_below[NB];
+    apply_V_vec<NREG, DB, NS>(V, dn_above, dn_below);
+    mat_vec<N, N>(ABE, dn_below, up_below);
+    SS_UNROLL_N(N)
+    for (int i = 0; i < N; ++i) up_below[i] = up_below[i] + src * SBE[i];
     if (URBAN) {
-      const double roof_a = 1.0 - in.roof_emissivity[sidx];
+      const double roof_a = 1.0 - dcur.roof_emissivity;
       double exposed_roof_frac;
-      if (jlay < nlay - 1)
-        exposed_roof_frac = ss_max(0.0, in.building_fraction[lay] - in.building_fraction[lay + 1]);
-      else
-        exposed_roof_frac = in.building_fraction[lay];
-      double sdna = 0.0, supa = 0.0, sdnb = 0.0, supb = 0.0;
+      if (jlay < nlay - 1) exposed_roof_frac = ss_max(0.0, dcur.g.building_fraction - bf_up);
+      else exposed_roof_frac = dcur.g.building_fraction;
+      double sdn = 0.0, sup = 0.0;
       SS_UNROLL_FULL
-      for (int s = 0; s < NS; ++s) { sdna += dna_below[N + s]; sdnb += dnb_below[N + s]; }
+      for (int s = 0; s < NS; ++s) sdn += dn_below[N + s];
       SS_UNROLL_FULL
       for (int s = 0; s < NS; ++s) {
-        double acca = 0.0, accb = 0.0;
+        double acc = 0.0;
         SS_UNROLL_FULL
-        for (int s2 = 0; s2 < NS; ++s2) {
-          acca += (roof_a * lg.hweight[s]) * dna_below[N + s2];
-          accb += (roof_a * lg.hweight[s]) * dnb_below[N + s2];
-        }
-        acca = acca + lg.hweight[s] * in.roof_emission[sidx] * exposed_roof_frac;
-        upa_below[N + s] = acca;
-        upb_below[N + s] = accb;
-        supa += acca;
-        supb += accb;
+        for (int s2 = 0; s2 < NS; ++s2) acc += (roof_a * lg.hweight[s]) * dn_below[N + s2];
+        acc = acc + src * (lg.hweight[s] * dcur.roof_emission * exposed_roof_frac);
+        up_below[N + s] = acc;
+        sup += acc;
       }
-      PUTL(fa, F_ROOF_IN, sdna);
-      PUTL(fa, F_ROOF_NET, sdna - supa);
-      PUTL(fb, F_ROOF_IN, sdnb);
-      PUTL(fb, F_ROOF_NET, sdnb - supb);
+      PUTL(F_ROOF_IN, sdn);
+      PUTL(F_ROOF_NET, sdn - sup);
     } else {
-      PUTL(fa, F_ROOF_IN, 0.0);
-      PUTL(fa, F_ROOF_NET, 0.0);
-      PUTL(fb, F_ROOF_IN, 0.0);
-      PUTL(fb, F_ROOF_NET, 0.0);
+      PUTL(F_ROOF_IN, 0.0);
+      PUTL(F_ROOF_NET, 0.0);
     }
 
-    {
-      // fluxes at the base of the layer (forest :547-553, :633-636)
-      double rhs[N], t2[N];
-      mat_vec<N, N>(T, dna_below, rhs);
-      mat_vec<N, N>(R, SabL, t2);
-      SS_UNROLL_N(N)
-      for (int i = 0; i < N; ++i) rhs[i] = (rhs[i] + t2[i] + Sl[i]);
-      lu_solve<N>(Den, rhs);
-      vec_copy<N>(rhs, dna_above);
-      mat_vec<N, N>(AabL, dna_above, upa_above);
-      SS_UNROLL_N(N)
-      for (int i = 0; i < N; ++i) upa_above[i] = upa_above[i] + SabL[i];
-      mat_vec<N, N>(T, dnb_below, rhs);
-      lu_solve<N>(Den, rhs);
-      vec_copy<N>(rhs, dnb_above);
-      mat_vec<N, N>(AabL, dnb_above, upb_above);
-    }
+    // ---- issue group 3 (LU of the denominator), work on group 2 ----
+    double DEN[N * N];
+    rec_load<N * N>(crec, st, CRec::DEN, DEN);
+    SS_LOAD_FENCE();
 
-    if (fa.f[F_FLUX_DN_LAYER_TOP]) {
-      double s = 0.0;
-      SS_UNROLL_N(N)
-      for (int i = 0; i < N; ++i) s += dna_below[i];
-      PUTL(fa, F_FLUX_DN_LAYER_TOP, s);
-      s = 0.0;
-      SS_UNROLL_N(N)
-      for (int i = 0; i < N; ++i) s += upa_below[i];
-      PUTL(fa, F_FLUX_UP_LAYER_TOP, s);
-      s = 0.0;
-      SS_UNROLL_N(N)
-      for (int i = 0; i < N; ++i) s += dna_above[i];
-      PUTL(fa, F_FLUX_DN_LAYER_BASE, s);
-      s = 0.0;
-      SS_UNROLL_N(N)
-      for (int i = 0; i < N; ++i) s += upa_above[i];
-      PUTL(fa, F_FLUX_UP_LAYER_BASE, s);
-    }
-    if (fb.f[F_FLUX_DN_LAYER_TOP]) {
-      double s = 0.0;
-      SS_UNROLL_N(N)
-      for (int i = 0; i < N; ++i) s += dnb_below[i];
-      PUTL(fb, F_FLUX_DN_LAYER_TOP, s);
-      s = 0.0;
-      SS_UNROLL_N(N)
-      for (int i = 0; i < N; ++i) s += upb_below[i];
-      PUTL(fb, F_FLUX_UP_LAYER_TOP, s);
-      s = 0.0;
-      SS_UNROLL_N(N)
-      for (int i = 0; i < N; ++i) s += dnb_above[i];
-      PUTL(fb, F_FLUX_DN_LAYER_BASE, s);
-      s = 0.0;
-      SS_UNROLL_N(N)
-      for (int i = 0; i < N; ++i) s += upb_above[i];
-      PUTL(fb, F_FLUX_UP_LAYER_BASE, s);
-    }
+    // fluxes at the base of the layer (forest :547-553, :633-636)
+    double rhs[N];
+    mat_vec<N, N>(T, dn_below, rhs);
+    SS_UNROLL_N(N)
+    for (int i = 0; i < N; ++i) rhs[i] = rhs[i] + src * RS[i];
 
-    double ifa[N], ifb[N];
-    {
-      double M[N * N], conv[N], Is[N];
-      rec_load<N * N>(lrec, stride, LRec::IFLUX, M);
-      rec_load<N>(lrec, stride, LRec::ISRC, Is);
-      SS_UNROLL_N(N)
-      for (int i = 0; i < N; ++i) conv[i] = dna_below[i] + upa_above[i];
-      mat_vec<N, N>(M, conv, ifa);
-      SS_UNROLL_N(N)
-      for (int i = 0; i < N; ++i) ifa[i] = ifa[i] + Is[i];
-      SS_UNROLL_N(N)
-      for (int i = 0; i < N; ++i) conv[i] = dnb_below[i] + upb_above[i];
-      mat_vec<N, N>(M, conv, ifb);
+    // ---- issue group 4 (a_above, source_above), work on group 3 ----
+    double AAB[N * N], SAB[N];
+    rec_load<N * N>(crec, st, CRec::AAB, AAB);
+    rec_load<N>(crec, st, CRec::SAB, SAB);
+    SS_LOAD_FENCE();
+
+    lu_solve<N>(DEN, rhs);
+    vec_copy<N>(rhs, dn_above);
+
+    // ---- issue group 5 (int_flux), work on group 4 ----
+    double IFLUX[N * N], ISRC[N];
+    rec_load<N * N>(lrec, st, LRec::IFLUX, IFLUX);
+    rec_load<N>(lrec, st, LRec::ISRC, ISRC);
+    SS_LOAD_FENCE();
+
+    mat_vec<N, N>(AAB, dn_above, up_above);
+    SS_UNROLL_N(N)
+    for (int i = 0; i < N; ++i) up_above[i] = up_above[i] + src * SAB[i];
+
+    if (FSEL(F_FLUX_DN_LAYER_TOP)) {
+      PUTL(F_FLUX_DN_LAYER_TOP, vec_sum<N>(dn_below));
+      PUTL(F_FLUX_UP_LAYER_TOP, vec_sum<N>(up_below));
+      PUTL(F_FLUX_DN_LAYER_BASE, vec_sum<N>(dn_above));
+      PUTL(F_FLUX_UP_LAYER_BASE, vec_sum<N>(up_above));
     }
+    double conv[N];
+    SS_UNROLL_N(N)
+    for (int i = 0; i < N; ++i) conv[i] = dn_below[i] + up_above[i];
+
+    // ---- issue group 1 of the next layer down and its scalars, work on group 5 ----
+    if (jlay > 0) {
+      const double* crec_n = L.col + rec_base(jlay - 1, L.maxlay, CRec::NELEM, cu);
+      din.load(in, lay - 1, (long)jb + (long)nspec * (lay - 1));
+      rec_load<N * N>(crec_n, st, CRec::ABE, ABE);
+      rec_load<N>(crec_n, st, CRec::SBE, SBE);
+    }
+    SS_LOAD_FENCE();
+    vf_up = dcur.g.veg_fraction;
+    bf_up = dcur.g.building_fraction;
+
+    double ifl[N];
+    mat_vec<N, N>(IFLUX, conv, ifl);
+    SS_UNROLL_N(N)
+    for (int i = 0; i < N; ++i) ifl[i] = ifl[i] + src * ISRC[i];
 
     // absorption (forest :571-590 / :658-672, urban :700-737 / :811-835)
-    const double air_ext = in.air_ext[sidx], air_ssa = in.air_ssa[sidx];
+    LwLayerProps<URBAN, NREG> p;
+    lw_layer_props<URBAN, NREG>(L, dcur, p);
+    const double air_ext = dcur.air_ext, air_ssa = dcur.air_ssa;
     {
-      double sa = 0.0, sb = 0.0;
+      double sa = 0.0;
       SS_UNROLL_FULL
-      for (int js = 0; js < NS; ++js) {
-        sa += ifa[js] * (1.0 / lg.mu[js]);
-        sb += ifb[js] * (1.0 / lg.mu[js]);
-      }
+      for (int js = 0; js < NS; ++js) sa += ifl[js] * (1.0 / lg.mu[js]);
       const double volume_emiss = p.frac[0] * (p.ext_reg[0] * (1.0 - p.ssa_reg[0]) * p.planck_reg[0]);
-      PUTL(fa, F_CLEAR_AIR_ABS, 0.0 + air_ext * (1.0 - air_ssa) * sa - (emiss_factor * volume_emiss) * p.g.dz);
-      PUTL(fb, F_CLEAR_AIR_ABS, 0.0 + air_ext * (1.0 - air_ssa) * sb);
+      PUTL(F_CLEAR_AIR_ABS, 0.0 + air_ext * (1.0 - air_ssa) * sa - src * ((emiss_factor * volume_emiss) * p.g.dz));
     }
     if (NREG > 1) {
-      double vaa_a = 0.0, va_a = 0.0, vaa_b = 0.0, va_b = 0.0;
+      double vaa = 0.0, va = 0.0;
       SS_UNROLL_FULL
       for (int jreg = 1; jreg < NREG; ++jreg) {
-        double sa = 0.0, sb = 0.0;
+        double sa = 0.0;
         SS_UNROLL_FULL
-        for (int js = 0; js < NS; ++js) {
-          sa += ifa[jreg * NS + js] * (1.0 / lg.mu[js]);
-          sb += ifb[jreg * NS + js] * (1.0 / lg.mu[js]);
-        }
+        for (int js = 0; js < NS; ++js) sa += ifl[jreg * NS + js] * (1.0 / lg.mu[js]);
         const double emiss_air = emiss_factor * p.frac[jreg] * p.ext_reg[0] * (1.0 - p.ssa_reg[0]) * p.vaplanck;
         const double emiss_veg = emiss_factor * p.frac[jreg] * p.g.veg_ext * (1.0 - p.vssa) * p.vplanck * p.od[jreg];
-        vaa_a = vaa_a + air_ext * (1.0 - air_ssa) * sa - emiss_air * p.g.dz;
-        va_a = va_a + p.g.veg_ext * (1.0 - p.vssa) * sa * p.od[jreg] - emiss_veg * p.g.dz;
-        vaa_b = vaa_b + air_ext * (1.0 - air_ssa) * sb;
-        va_b = va_b + p.g.veg_ext * (1.0 - p.vssa) * sb * p.od[jreg];
+        vaa = vaa + air_ext * (1.0 - air_ssa) * sa - src * (emiss_air * p.g.dz);
+        va = va + p.g.veg_ext * (1.0 - p.vssa) * sa * p.od[jreg] - src * (emiss_veg * p.g.dz);
       }
-      PUTL(fa, F_VEG_AIR_ABS, vaa_a);
-      PUTL(fa, F_VEG_ABS, va_a);
-      PUTL(fb, F_VEG_AIR_ABS, vaa_b);
-      PUTL(fb, F_VEG_ABS, va_b);
+      PUTL(F_VEG_AIR_ABS, vaa);
+      PUTL(F_VEG_ABS, va);
     } else {
-      PUTL(fa, F_VEG_AIR_ABS, 0.0);
-      PUTL(fa, F_VEG_ABS, 0.0);
-      PUTL(fb, F_VEG_AIR_ABS, 0.0);
-      PUTL(fb, F_VEG_ABS, 0.0);
+      PUTL(F_VEG_AIR_ABS, 0.0);
+      PUTL(F_VEG_ABS, 0.0);
     }
     if (URBAN) {
-      double wall_in_a = 0.0, wall_in_b = 0.0, npw_sum = 0.0;
+      double wall_in = 0.0, npw_sum = 0.0;
       SS_UNROLL_FULL
       for (int jreg = 0; jreg < NREG; ++jreg) {
-        double sa = 0.0, sb = 0.0;
+        double sa = 0.0;
         SS_UNROLL_FULL
-        for (int js = 0; js < NS; ++js) {
-          sa += ifa[jreg * NS + js] * lg.tan_ang[js];
-          sb += ifb[jreg * NS + js] * lg.tan_ang[js];
-        }
-        wall_in_a = wall_in_a + p.f_wall[jreg] * sa;
-        wall_in_b = wall_in_b + p.f_wall[jreg] * (sb);
+        for (int js = 0; js < NS; ++js) sa += ifl[jreg * NS + js] * lg.tan_ang[js];
+        wall_in = wall_in + p.f_wall[jreg] * sa;
         npw_sum += p.npw[jreg];
       }
-      const double emiss_wall = (npw_sum * lg.vadjustment) * in.wall_emission[sidx];
-      PUTL(fa, F_WALL_IN, wall_in_a);
-      PUTL(fa, F_WALL_NET, wall_in_a * in.wall_emissivity[sidx] - emiss_wall * p.g.dz);
-      PUTL(fb, F_WALL_IN, wall_in_b);
-      PUTL(fb, F_WALL_NET, wall_in_b * in.wall_emissivity[sidx]);
+      const double emiss_wall = (npw_sum * lg.vadjustment) * dcur.wall_emission;
+      PUTL(F_WALL_IN, wall_in);
+      PUTL(F_WALL_NET, wall_in * dcur.wall_emissivity - src * (emiss_wall * p.g.dz));
     } else {
-      PUTL(fa, F_WALL_IN, 0.0);
-      PUTL(fa, F_WALL_NET, 0.0);
-      PUTL(fb, F_WALL_IN, 0.0);
-      PUTL(fb, F_WALL_NET, 0.0);
+      PUTL(F_WALL_IN, 0.0);
+      PUTL(F_WALL_NET, 0.0);
     }
   }
 
   // ground (forest :599-610 / :680-694, urban :741-752 / :845-858)
   {
-    double s2a = 0.0, s3a = 0.0, s2b = 0.0, s3b = 0.0, gvda = 0.0, gvdb = 0.0;
-    SS_UNROLL_N(N)
-    for (int i = 0; i < N; ++i) { s2a += dna_above[i]; s2b += dnb_above[i]; }
-    SS_UNROLL_N(N)
-    for (int i = 0; i < N; ++i) { s3a += upa_above[i]; s3b += upb_above[i]; }
-    PUTC(fa, F_GROUND_DN, s2a);
-    PUTC(fa, F_GROUND_NET, s2a - s3a);
-    PUTC(fb, F_GROUND_DN, s2b);
-    PUTC(fb, F_GROUND_NET, s2b - s3b);
+    const double s2 = vec_sum<N>(dn_above), s3 = vec_sum<N>(up_above);
+    PUTC(F_GROUND_DN, s2);
+    PUTC(F_GROUND_NET, s2 - s3);
+    // own accumulation (urban: starts from zero in both passes)
+    double gvd_own = 0.0;
     SS_UNROLL_FULL
     for (int jreg = 0; jreg < NREG; ++jreg) {
       SS_UNROLL_FULL
       for (int js = 0; js < NS; ++js) {
         const int ifr = js + jreg * NS;
-        gvda = gvda + (dna_above[ifr] + upa_above[ifr]) * lg.tan_ang[js] / kPi;
+        gvd_own = gvd_own + (dn_above[ifr] + up_above[ifr]) * lg.tan_ang[js] / kPi;
       }
     }
-    // second accumulation separately, in the reference's order
-    double gvd2 = URBAN ? 0.0 : gvda;
-    SS_UNROLL_FULL
-    for (int jreg = 0; jreg < NREG; ++jreg) {
-      SS_UNROLL_FULL
-      for (int js = 0; js < NS; ++js) {
-        const int ifr = js + jreg * NS;
-        gvd2 = gvd2 + (dnb_above[ifr] + upb_above[ifr]) * lg.tan_ang[js] / kPi;
-      }
-    }
-    gvdb = gvd2;
     if (URBAN) {
-      PUTC(fa, F_GROUND_VERTICAL_DIFF, gvda);
-      PUTC(fb, F_GROUND_VERTICAL_DIFF, gvdb);
+      PUTC(F_GROUND_VERTICAL_DIFF, gvd_own);
     } else {
-      // forest: the incoming pass also accumulates into lw_internal and
-      // lw_norm%ground_vertical_diff stays zero (radsurf_forest_lw.F90:691)
-      PUTC(fa, F_GROUND_VERTICAL_DIFF, gvdb);
-      PUTC(fb, F_GROUND_VERTICAL_DIFF, 0.0);
+      // forest: the incoming pass accumulates ON TOP of the internal pass's value,
+      // into lw_internal, and lw_norm%ground_vertical_diff stays zero
+      // (radsurf_forest_lw.F90:691): the incoming-pass lane takes the internal
+      // value from its partner lane and writes both members
+      const double gvda = lw_partner_value(gvd_own, pass, slot);
+      if (!internal) {
+        double gvd2 = gvda;
+        SS_UNROLL_FULL
+        for (int jreg = 0; jreg < NREG; ++jreg) {
+          SS_UNROLL_FULL
+          for (int js = 0; js < NS; ++js) {
+            const int ifr = js + jreg * NS;
+            gvd2 = gvd2 + (dn_above[ifr] + up_above[ifr]) * lg.tan_ang[js] / kPi;
+          }
+        }
+        if (L.flux_a.f[F_GROUND_VERTICAL_DIFF]) L.flux_a.f[F_GROUND_VERTICAL_DIFF][cidx] = gvd2;
+        if (L.flux_b.f[F_GROUND_VERTICAL_DIFF]) L.flux_b.f[F_GROUND_VERTICAL_DIFF][cidx] = 0.0;
+      }
     }
   }
 #undef PUTC
 #undef PUTL
+#undef FSEL
+}
+
+// Whole column on one lane (host emulation and small problems)
+template <bool URBAN, int NREG, int NS>
+SS_HD void column_unit_lw(const Launch& L, int cu) {
+  double slot = 0.0;
+  column_up_lw<URBAN, NREG, NS>(L, cu);
+  column_down_lw<URBAN, NREG, NS>(L, cu, 0, &slot);
+  column_down_lw<URBAN, NREG, NS>(L, cu, 1, &slot);
 }
 
 }  // namespace ss

@@ -39,6 +39,11 @@
 // it in the instruction stream (no hardware wait): used to issue a whole group
 // of loads ahead of the arithmetic that overlaps with their latency.
 #if defined(__HIP_DEVICE_COMPILE__)
+#define SS_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SS_SCHED_FENCE() do {} while (0)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
 #define SS_LOAD_FENCE() asm volatile("" ::: "memory")
 #else
 #define SS_LOAD_FENCE() do {} while (0)

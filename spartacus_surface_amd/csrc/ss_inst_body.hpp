@@ -28,12 +28,12 @@ __global__ void __launch_bounds__(kBlock, SS_MIN_WAVES_LAYER) k_layer(const Laun
   else layer_unit_sw<U, R, NS>(L, cu, (int)blockIdx.y);
 }
 
-// upward sweep (adding method); for the longwave still the whole column
+// upward sweep (adding method)
 template <bool U, int R, int NS, bool LW>
 __global__ void __launch_bounds__(kBlock, SS_MIN_WAVES_COLUMN) k_column(const Launch L) {
   const int cu = blockIdx.x * kBlock + threadIdx.x;
   if (cu >= L.ncu) return;
-  if (LW) column_unit_lw<U, R, NS>(L, cu);
+  if (LW) column_up_lw<U, R, NS>(L, cu);
   else column_up_sw<U, R, NS>(L, cu);
 }
 
@@ -43,7 +43,8 @@ __global__ void __launch_bounds__(kBlock, SS_MIN_WAVES_DOWN) k_down(const Launch
   const int unit = blockIdx.x * kBlock + threadIdx.x;   // (column unit, pass), pass fastest
   const int cu = unit >> 1;
   if (cu >= L.ncu) return;
-  if (!LW) column_down_sw<U, R, NS>(L, cu, unit & 1);
+  if (LW) column_down_lw<U, R, NS>(L, cu, unit & 1, nullptr);
+  else column_down_sw<U, R, NS>(L, cu, unit & 1);
 }
 
 template <int NS>
@@ -56,7 +57,7 @@ void launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev) {
   hipLaunchKernelGGL((k_column<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx), dim3(kBlock), 0,
                      stream, L);
   if (ev) hipEventRecord(ev[2], stream);
-  if (!SS_INST_LW) {
+  {
     const unsigned gd = (unsigned)((2L * L.ncu + kBlock - 1) / kBlock);
     hipLaunchKernelGGL((k_down<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gd), dim3(kBlock), 0,
                        stream, L);

@@ -72,9 +72,9 @@ inline int lay_nelem(bool lw, const ClassKey& k) {
 }
 inline int col_nelem(bool lw, const ClassKey& k) {
   const int n = k.nreg * k.ns, d = k.nreg;
-  // LW: a_above + source_above; SW: a_above, d_above, LU(den), a_below, d_below
+  // LW: a_above, LU(den), a_below + 3 vectors; SW: a_above, d_above, LU(den), a_below, d_below
   auto ev = [](int x) { return (x + 1) & ~1; };
-  return lw ? ev(n * n) + ev(n) : 3 * ev(n * n) + 2 * ev(n * d);
+  return lw ? 3 * ev(n * n) + 3 * ev(n) : 3 * ev(n * n) + 2 * ev(n * d);
 }
 
 // Runtime (urban, nreg, ns) -> template instance

@@ -27,34 +27,64 @@ struct LwLayerProps {
   double vssa, vplanck, vaplanck;
 };
 
+// Raw per-layer inputs of the longwave units (loads only, so that they can be
+// issued ahead of the arithmetic)
 template <bool URBAN, int NREG>
-SS_HD void lw_layer_props(const Launch& L, int lay, long sidx, LwLayerProps<URBAN, NREG>& p) {
-  const Inputs& in = L.in;
-  p.g = load_layer_geom<URBAN, NREG>(in, lay);
+struct LwLayerIn {
+  LayerGeom g;
+  double air_ext, air_ssa, veg_ssa, veg_planck, veg_air_planck, clear_air_planck;
+  double roof_emissivity, roof_emission, wall_emissivity, wall_emission;
+  SS_HD void load(const Inputs& in, int lay, long sidx) {
+    g = load_layer_geom<URBAN, NREG>(in, lay);
+    air_ext = in.air_ext[sidx];
+    air_ssa = in.air_ssa[sidx];
+    veg_ssa = (NREG > 1) ? in.veg_ssa[sidx] : 0.0;
+    veg_planck = (NREG > 1) ? in.veg_planck[sidx] : 0.0;
+    veg_air_planck = (NREG > 1) ? in.veg_air_planck[sidx] : 0.0;
+    clear_air_planck = in.clear_air_planck[sidx];
+    roof_emissivity = roof_emission = wall_emissivity = wall_emission = 0.0;
+    if (URBAN) {
+      roof_emissivity = in.roof_emissivity[sidx];
+      roof_emission = in.roof_emission[sidx];
+      wall_emissivity = in.wall_emissivity[sidx];
+      wall_emission = in.wall_emission[sidx];
+    }
+  }
+};
+
+template <bool URBAN, int NREG>
+SS_HD void lw_layer_props(const Launch& L, const LwLayerIn<URBAN, NREG>& r, LwLayerProps<URBAN, NREG>& p) {
+  p.g = r.g;
   region_fractions<URBAN, true, NREG>(p.g.veg_fraction, p.g.building_fraction, p.frac);
   norm_perimeters<URBAN, NREG>(L.cfg, p.g, p.np, p.npw);
   od_scaling<NREG>(p.g.veg_fsd, p.od);
-  p.vssa = (NREG > 1) ? in.veg_ssa[sidx] : 0.0;
-  p.vplanck = (NREG > 1) ? in.veg_planck[sidx] : 0.0;
-  p.vaplanck = (NREG > 1) ? in.veg_air_planck[sidx] : 0.0;
-  region_optics<NREG>(in.air_ext[sidx], in.air_ssa[sidx], p.g.veg_ext, p.vssa, p.od,
-                      p.ext_reg, p.ssa_reg);
-  p.planck_reg[0] = in.clear_air_planck[sidx];
+  p.vssa = r.veg_ssa;
+  p.vplanck = r.veg_planck;
+  p.vaplanck = r.veg_air_planck;
+  region_optics<NREG>(r.air_ext, r.air_ssa, p.g.veg_ext, p.vssa, p.od, p.ext_reg, p.ssa_reg);
+  p.planck_reg[0] = r.clear_air_planck;
   // (radsurf_forest_lw.F90:283-300)
   SS_UNROLL_FULL
-  for (int r = 1; r < NREG; ++r)
-    p.planck_reg[r] = (p.ext_reg[0] * (1.0 - p.ssa_reg[0]) * p.vaplanck
+  for (int k = 1; k < NREG; ++k)
+    p.planck_reg[k] = (p.ext_reg[0] * (1.0 - p.ssa_reg[0]) * p.vaplanck
                        + ((NREG == 2) ? p.g.veg_ext * (1.0 - p.vssa) * p.vplanck
-                                      : p.od[r] * p.g.veg_ext * (1.0 - p.vssa) * p.vplanck))
-                      / ss_max(p.ext_reg[r] * (1.0 - p.ssa_reg[r]), 1.0e-8);
+                                      : p.od[k] * p.g.veg_ext * (1.0 - p.vssa) * p.vplanck))
+                      / ss_max(p.ext_reg[k] * (1.0 - p.ssa_reg[k]), 1.0e-8);
   SS_UNROLL_FULL
-  for (int r = 0; r < NREG; ++r) {
+  for (int k = 0; k < NREG; ++k) {
     if (URBAN)   // radsurf_urban_lw.F90:372-381 (note vadjustment2)
-      p.f_wall[r] = (p.frac[r] <= L.cfg.min_vegetation_fraction)
-                        ? 0.0 : p.npw[r] * L.lg.vadjustment2 / (kPi * p.frac[r]);
+      p.f_wall[k] = (p.frac[k] <= L.cfg.min_vegetation_fraction)
+                        ? 0.0 : p.npw[k] * L.lg.vadjustment2 / (kPi * p.frac[k]);
     else
-      p.f_wall[r] = 0.0;
+      p.f_wall[k] = 0.0;
   }
+}
+
+template <bool URBAN, int NREG>
+SS_HD void lw_layer_props(const Launch& L, int lay, long sidx, LwLayerProps<URBAN, NREG>& p) {
+  LwLayerIn<URBAN, NREG> r;
+  r.load(L.in, lay, sidx);
+  lw_layer_props<URBAN, NREG>(L, r, p);
 }
 
 template <bool URBAN, int NREG, int NS>

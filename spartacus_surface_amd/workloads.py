@@ -124,7 +124,7 @@ def _urban_columns(rng, ncol, nsw, nlw):
     return base, cp, alb
 
 
-def c3_vegetated_urban(ncol=1_000_000, seed=12345):
+def c3_vegetated_urban(ncol=1_000_000, seed=12345, nstream=2):
     """C3: test/urban vegetated-urban column on 10 layers, 3 regions, 2 streams,
     1 SW + 1 LW band, SW+LW; per-column multiplicative jitter U(0.9,1.1) on
     building/vegetation fractions, scales and albedos (building+veg clipped to
@@ -132,8 +132,8 @@ def c3_vegetated_urban(ncol=1_000_000, seed=12345):
     rng = np.random.default_rng(seed)
     cfg = Config(do_sw=True, do_lw=True, do_vegetation=True, do_urban=True,
                  n_vegetation_region_forest=2, n_vegetation_region_urban=2, nsw=1, nlw=1,
-                 n_stream_sw_forest=2, n_stream_sw_urban=2, n_stream_lw_forest=2,
-                 n_stream_lw_urban=2).consolidate()
+                 n_stream_sw_forest=nstream, n_stream_sw_urban=nstream, n_stream_lw_forest=nstream,
+                 n_stream_lw_urban=nstream).consolidate()
     L = 10
     base, cpa, alb = _urban_columns(rng, ncol, 1, 1)
     cp = CanopyProperties().set_layers(np.full(ncol, L, dtype=np.int32))
