@@ -214,6 +214,21 @@ def main():
         elapsed = float(t.item())
     nfail = plan.eigen_failures()
 
+    # two extra, untimed steps with strictly serial kernels (one stream): per-kernel
+    # durations without the chunk overlap of the timed region
+    pipes = int(os.environ.get("SPARTACUS_PIPES", "2"))
+    serial_ms = None
+    if pipes > 1:
+        plan.set_pipes(1)
+        serial_ms = {k: 0.0 for k in fam_ms}
+        serial_n = dict.fromkeys(fam_ms, 0)
+        for _ in range(2):
+            plan.solve()
+            for k in fam_ms:
+                serial_ms[k] += plan.kernel_ms(k)
+                serial_n[k] += int(plan.kernel_ms(k + ".launches"))
+        plan.synchronize()
+
     if rank == 0:
         total_cols = args.columns * world * args.steps
         value = total_cols / elapsed
@@ -247,9 +262,24 @@ def main():
                      "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": fpc * args.columns / (kernel_total_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                      "flops_per_column_model": fpc},
+            "streams": pipes,
             "kernel_ms_per_step": {k: v / args.steps for k, v in fam_ms.items()},
             "eigen_failures": nfail,
         }
+        if serial_ms is not None:
+            sd = max(serial_ms, key=lambda k: serial_ms[k])
+            s_avg = serial_ms[sd] / max(1, serial_n[sd])
+            s_cols = args.columns * 2 / max(1, serial_n[sd])
+            s_ach = bpc * s_cols / (s_avg * 1e-3) / 1e9
+            s_tot = sum(serial_ms.values()) / 2
+            line["kernel_ms_per_step_serial"] = {k: v / 2 for k, v in serial_ms.items()}
+            line["roofline_serial"] = {
+                "note": "same kernels on one stream (2 extra untimed steps): no overlap between chunks",
+                "bound": "hbm", "kernel": sd, "achieved": s_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": s_ach / HBM_PEAK_GBS, "avg_launch_ms": s_avg,
+                "traffic": measured_traffic(sd, s_cols, args.workload)[0],
+                "fp64_tflops": fpc * args.columns / (s_tot * 1e-3) / 1e12,
+                "fp64_frac": fpc * args.columns / (s_tot * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, min(args.cpu_sample, args.columns))
             line["pcie_inclusive"] = host_entry_rate(min(args.columns, 200_000))

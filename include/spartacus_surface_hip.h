@@ -267,6 +267,13 @@ int ss_plan_last_kernel_ms(ss_plan *plan, const char *name, double *ms);
  * in the last solve (the reference silently ignores these:
  * radtool_eigen_decomposition.F90:498-510, calc_matrices_sw_eig.F90:183). */
 int ss_plan_eigen_failures(ss_plan *plan, int64_t *count);
+/* Number of concurrent HIP streams ("pipes") the next ss_plan_solve spreads its
+ * chunk launches over: 1 = strictly serial kernels (what per-kernel profiling
+ * wants), 2 (default, env SPARTACUS_PIPES) = the memory-bound column kernels of
+ * one chunk overlap with the arithmetic-bound layer kernel of the next.  No
+ * counterpart in the reference (its concurrency is the OpenMP block loop,
+ * driver/spartacus_surface_driver.F90:206-233). */
+int ss_plan_set_pipes(ss_plan *plan, int32_t npipes);
 /* Raw device pointer of an output / input mirror by name, e.g.
  * "sw_norm_dir.ground_dn", "bc_out.sw_albedo" (for RCCL gathers). */
 int ss_plan_device_ptr(ss_plan *plan, const char *name, void **ptr,

@@ -40,6 +40,18 @@ hipStream_t stream() {
   return g_stream;
 }
 
+// Worker streams of the solve ("pipes" of ss_plan_impl.hpp): pipe 0 is the
+// library's main stream, further pipes fork from it and join it again.
+constexpr int kMaxPipes = 2;
+hipStream_t g_pipe[kMaxPipes] = {nullptr, nullptr};
+hipEvent_t g_fork_ev = nullptr, g_join_ev[kMaxPipes] = {nullptr, nullptr};
+
+hipStream_t pipe_stream(int p) {
+  if (p <= 0) return stream();
+  if (!g_pipe[p]) HIP_CHECK_THROW(hipStreamCreateWithFlags(&g_pipe[p], hipStreamNonBlocking));
+  return g_pipe[p];
+}
+
 // ---- misc kernels ----
 __global__ void __launch_bounds__(256) k_flat(const ss::MiscLaunch M) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -164,7 +176,22 @@ struct HipBackend {
     if (S.nlays > 0)
       hipLaunchKernelGGL(k_spectrum_lay, dim3((S.nlays + 255) / 256), dim3(256), 0, stream(), S);
   }
-  static void launch_solver(const ss::ClassKey& key, bool lw, const ss::Launch& L, Timers& t) {
+  // the pipes start after everything queued on the main stream so far ...
+  static void fork(int npipes) {
+    if (npipes <= 1) return;
+    if (!g_fork_ev) HIP_CHECK_THROW(hipEventCreateWithFlags(&g_fork_ev, hipEventDisableTiming));
+    HIP_CHECK_THROW(hipEventRecord(g_fork_ev, stream()));
+    for (int p = 1; p < npipes; ++p) HIP_CHECK_THROW(hipStreamWaitEvent(pipe_stream(p), g_fork_ev, 0));
+  }
+  // ... and the main stream continues after all of them
+  static void join(int npipes) {
+    for (int p = 1; p < npipes; ++p) {
+      if (!g_join_ev[p]) HIP_CHECK_THROW(hipEventCreateWithFlags(&g_join_ev[p], hipEventDisableTiming));
+      HIP_CHECK_THROW(hipEventRecord(g_join_ev[p], pipe_stream(p)));
+      HIP_CHECK_THROW(hipStreamWaitEvent(stream(), g_join_ev[p], 0));
+    }
+  }
+  static void launch_solver(const ss::ClassKey& key, bool lw, const ss::Launch& L, Timers& t, int pipe) {
     ss::SolverLauncher fn = nullptr;
     if (!lw) {
       if (!key.urban) fn = key.nreg == 2 ? ss::launch_sw_forest_r2 : ss::launch_sw_forest_r3;
@@ -174,7 +201,7 @@ struct HipBackend {
       else fn = key.nreg == 1 ? ss::launch_lw_urban_r1 : key.nreg == 2 ? ss::launch_lw_urban_r2 : ss::launch_lw_urban_r3;
     }
     hipEvent_t ev[4] = {t.next(), t.next(), t.next(), t.next()};
-    fn(key.ns, L, stream(), ev);
+    fn(key.ns, L, pipe_stream(pipe), ev);
     t.spans.push_back({lw ? FAM_LW_LAYER : FAM_SW_LAYER, ev[0], ev[1]});
     t.spans.push_back({lw ? FAM_LW_COLUMN : FAM_SW_COLUMN, ev[1], ev[2]});
     t.spans.push_back({lw ? FAM_LW_DOWN : FAM_SW_DOWN, ev[2], ev[3]});
@@ -318,6 +345,11 @@ int ss_plan_last_kernel_ms(ss_plan* plan, const char* name, double* ms) {
 int ss_plan_eigen_failures(ss_plan* plan, int64_t* count) {
   if (!plan || !count) return SS_ERR_BAD_ARGUMENT;
   return guarded([&]() { *count = plan->impl.eigen_failures(); return (int)SS_OK; });
+}
+
+int ss_plan_set_pipes(ss_plan* plan, int32_t npipes) {
+  if (!plan || npipes < 1) return SS_ERR_BAD_ARGUMENT;
+  return guarded([&]() { return plan->impl.set_pipes(npipes); });
 }
 
 int ss_plan_device_ptr(ss_plan* plan, const char* name, void** ptr, int64_t* nelem) {

@@ -16,12 +16,13 @@ namespace ss {
 template <int N>
 struct LwColRec {
   static constexpr int AAB = 0;                       // a_above(l)        N x N
-  static constexpr int DEN = AAB + rec_even(N * N);   // lu(denominator(l)) N x N
-  static constexpr int ABE = DEN + rec_even(N * N);   // a_below(l+1)      N x N (canopy part)
+  static constexpr int PDN = AAB + rec_even(N * N);   // P = Den^-1 T      N x N   (Den = I - a_above R)
+  static constexpr int ABE = PDN + rec_even(N * N);   // a_below(l+1)      N x N (canopy part)
   static constexpr int SAB = ABE + rec_even(N * N);   // source_above(l)   N
   static constexpr int SBE = SAB + rec_even(N);       // source_below(l+1) N (canopy part)
-  static constexpr int RS = SBE + rec_even(N);        // R source_above + source_lay  N
-  static constexpr int NELEM = RS + rec_even(N);
+  static constexpr int RSD = SBE + rec_even(N);       // Den^-1 (R source_above + source_lay)  N
+  static constexpr int NELEM = RSD + rec_even(N);
+  // flux at the layer base in the downward sweep = P flux_top + RSD (forest :547-553)
 };
 
 // denominator LU, a_below(l+1), source_below(l+1) (canopy parts) of layer l
@@ -56,7 +57,7 @@ SS_HD void lw_adding_step(const double* Aab, const double* Sab, const double* R,
 }
 
 // ---- section 4: adding method with sources, upward (k_up) ----
-template <bool URBAN, int NREG, int NS>
+template <bool URBAN, int NREG, int NS, bool FUSED = false>
 SS_HD void column_up_lw(const Launch& L, int cu) {
   constexpr int N = NREG * NS;
   constexpr int DB = URBAN ? NREG + 1 : NREG;
@@ -93,6 +94,7 @@ SS_HD void column_up_lw(const Launch& L, int cu) {
   }
 
   for (int jlay = 0; jlay < nlay; ++jlay) {
+    if (FUSED) layer_unit_lw<URBAN, NREG, NS>(L, cu, jlay);
     const double* lrec = L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu);
     double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
     const int lay = l0 + jlay;
@@ -106,15 +108,17 @@ SS_HD void column_up_lw(const Launch& L, int cu) {
       rec_store<N * N>(crec, stride, CRec::AAB, Aab);
       rec_store<N>(crec, stride, CRec::SAB, Sab);
       lw_adding_step<N>(Aab, Sab, R, T, Sl, Den, Abe, Sbe);
-      rec_store<N * N>(crec, stride, CRec::DEN, Den);
       rec_store<N * N>(crec, stride, CRec::ABE, Abe);
       rec_store<N>(crec, stride, CRec::SBE, Sbe);
-      // term of the downward sweep that does not depend on the incoming flux
+      // operators of the downward sweep
+      lu_solve_mat<N, N>(Den, T);                 // P = Den^-1 T (T is dead afterwards)
+      rec_store<N * N>(crec, stride, CRec::PDN, T);
       double rs[N];
       mat_vec<N, N>(R, Sab, rs);
       SS_UNROLL_N(N)
       for (int i = 0; i < N; ++i) rs[i] = rs[i] + Sl[i];
-      rec_store<N>(crec, stride, CRec::RS, rs);
+      lu_solve<N>(Den, rs);
+      rec_store<N>(crec, stride, CRec::RSD, rs);
     }
     {
       double U[NREG * DB], V[DB * NREG];
@@ -251,10 +255,10 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
     const long sidx = (long)jb + (long)nspec * lay;
     const LwLayerIn<URBAN, NREG> dcur = din;
 
-    // ---- issue group 2 (T, R source_above + source_lay), work on group 1 ----
-    double T[N * N], RS[N];
-    rec_load<N * N>(lrec, st, LRec::T, T);
-    rec_load<N>(crec, st, CRec::RS, RS);
+    // ---- issue group 2 (P, RSD), work on group 1 ----
+    double P[N * N], RSD[N];
+    rec_load<N * N>(crec, st, CRec::PDN, P);
+    rec_load<N>(crec, st, CRec::RSD, RSD);
     SS_LOAD_FENCE();
 
     double U[NREG * DB], V[DB * NREG];
@@ -289,27 +293,18 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
       PUTL(F_ROOF_NET, 0.0);
     }
 
-    // ---- issue group 3 (LU of the denominator), work on group 2 ----
-    double DEN[N * N];
-    rec_load<N * N>(crec, st, CRec::DEN, DEN);
-    SS_LOAD_FENCE();
-
-    // fluxes at the base of the layer (forest :547-553, :633-636)
-    double rhs[N];
-    mat_vec<N, N>(T, dn_below, rhs);
-    SS_UNROLL_N(N)
-    for (int i = 0; i < N; ++i) rhs[i] = rhs[i] + src * RS[i];
-
-    // ---- issue group 4 (a_above, source_above), work on group 3 ----
+    // ---- issue group 3 (a_above, source_above), work on group 2 ----
     double AAB[N * N], SAB[N];
     rec_load<N * N>(crec, st, CRec::AAB, AAB);
     rec_load<N>(crec, st, CRec::SAB, SAB);
     SS_LOAD_FENCE();
 
-    lu_solve<N>(DEN, rhs);
-    vec_copy<N>(rhs, dn_above);
+    // flux at the base of the layer (forest :547-553, :633-636)
+    mat_vec<N, N>(P, dn_below, dn_above);
+    SS_UNROLL_N(N)
+    for (int i = 0; i < N; ++i) dn_above[i] = dn_above[i] + src * RSD[i];
 
-    // ---- issue group 5 (int_flux), work on group 4 ----
+    // ---- issue group 4 (int_flux), work on group 3 ----
     double IFLUX[N * N], ISRC[N];
     rec_load<N * N>(lrec, st, LRec::IFLUX, IFLUX);
     rec_load<N>(lrec, st, LRec::ISRC, ISRC);
@@ -329,7 +324,7 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
     SS_UNROLL_N(N)
     for (int i = 0; i < N; ++i) conv[i] = dn_below[i] + up_above[i];
 
-    // ---- issue group 1 of the next layer down and its scalars, work on group 5 ----
+    // ---- issue group 1 of the next layer down and its scalars, work on group 4 ----
     if (jlay > 0) {
       const double* crec_n = L.col + rec_base(jlay - 1, L.maxlay, CRec::NELEM, cu);
       din.load(in, lay - 1, (long)jb + (long)nspec * (lay - 1));

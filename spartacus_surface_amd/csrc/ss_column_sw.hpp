@@ -27,10 +27,15 @@ template <int N, int D>
 struct SwColRec {
   static constexpr int AAB = 0;                           // a_above(l)        N x N
   static constexpr int DAB = AAB + rec_even(N * N);       // d_above(l)        N x D
-  static constexpr int DEN = DAB + rec_even(N * D);       // lu(denominator(l)) N x N
-  static constexpr int ABE = DEN + rec_even(N * N);       // a_below(l+1)      N x N (canopy part)
+  static constexpr int PDN = DAB + rec_even(N * D);       // P = Den^-1 T      N x N
+  static constexpr int QDN = PDN + rec_even(N * N);       // Q = Den^-1 (R d_above E + S_dn)  N x D
+  static constexpr int ABE = QDN + rec_even(N * D);       // a_below(l+1)      N x N (canopy part)
   static constexpr int DBE = ABE + rec_even(N * N);       // d_below(l+1)      N x D (canopy part)
   static constexpr int NELEM = DBE + rec_even(N * D);
+  // Den = I - a_above R.  The downward sweep needs the flux at the layer base,
+  //   diff_base = Den^-1 (T diff_top + R d_above E dir_top + S_dn dir_top) = P diff_top + Q dir_top,
+  // so the two operators are stored instead of LU(Den): the sweep then reads
+  // neither T, R nor S_dn of the layer record.
 };
 
 // Common per-unit context of the two column kernels
@@ -65,7 +70,10 @@ struct SwColCtx {
 };
 
 // ---- section 4: adding method upward (k_up) ----
-template <bool URBAN, int NREG, int NS>
+// FUSED: the lane first computes the layer matrices of each layer itself
+// (layer_unit_sw) and reads them back from its own scratch record, which is
+// then still in cache.
+template <bool URBAN, int NREG, int NS, bool FUSED = false>
 SS_HD void column_up_sw(const Launch& L, int cu) {
   constexpr int N = NREG * NS, D = NREG;
   constexpr int DB = URBAN ? NREG + 1 : NREG;
@@ -97,6 +105,7 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
   }
 
   for (int jlay = 0; jlay < nlay; ++jlay) {
+    if (FUSED) layer_unit_sw<URBAN, NREG, NS>(L, cu, jlay);
     const double* lrec = L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu);
     double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
     const long sidx = (long)jb + (long)nspec * (l0 + jlay);
@@ -114,7 +123,10 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
       SS_UNROLL_N(N)
       for (int j = 0; j < N; ++j) SS_E(Den, j, j, N) = 1.0 + SS_E(Den, j, j, N);
       lu_factor<N>(Den);
-      rec_store<N * N>(crec, stride, CRec::DEN, Den);
+      // P = Den^-1 T
+      mat_copy<N, N>(T, X);
+      lu_solve_mat<N, N>(Den, X);
+      rec_store<N * N>(crec, stride, CRec::PDN, X);
       // a_below = R + T Den^-1 (a_above T)
       mat_mul<N, N, N>(Aab, T, X);
       lu_solve_mat<N, N>(Den, X);
@@ -127,6 +139,15 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
       rec_load<D * D>(lrec, stride, LRec::EDIR, E);
       rec_load<N * D>(lrec, stride, LRec::SDN, S);
       mat_mul<N, D, D>(Dab, E, Y);
+      {
+        // Q = Den^-1 (R (d_above E) + S_dn)
+        double Q[N * D];
+        mat_mul<N, N, D>(R, Y, Q);
+        SS_UNROLL_FULL
+        for (int k = 0; k < N * D; ++k) Q[k] = Q[k] + S[k];
+        lu_solve_mat<N, D>(Den, Q);
+        rec_store<N * D>(crec, stride, CRec::QDN, Q);
+      }
       mat_mul_acc<N, N, D>(Aab, S, Y);
       lu_solve_mat<N, D>(Den, Y);
       rec_load<N * D>(lrec, stride, LRec::SUP, S);
@@ -291,11 +312,11 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
     const SwDownIn<URBAN, NREG> dcur = din;
     const LayerGeom g = dcur.g;
 
-    // ---- issue group 2 (E, d_above, S_dn), work on group 1 (a_below, d_below) ----
-    double E[D * D], DAB[N * D], SDN[N * D];
+    // ---- issue group 2 (E, d_above, Q), work on group 1 (a_below, d_below) ----
+    double E[D * D], DAB[N * D], Q[N * D];
     rec_load<D * D>(lrec, st, LRec::EDIR, E);
     rec_load<N * D>(crec, st, CRec::DAB, DAB);
-    rec_load<N * D>(lrec, st, LRec::SDN, SDN);
+    rec_load<N * D>(crec, st, CRec::QDN, Q);
     SS_LOAD_FENCE();
 
     double U[NREG * DB], V[DB * NREG];
@@ -348,9 +369,9 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
       }
     }
 
-    // ---- issue group 3 (T), work on group 2 ----
-    double T[N * N];
-    rec_load<N * N>(lrec, st, LRec::T, T);
+    // ---- issue group 3 (P), work on group 2 ----
+    double P[N * N];
+    rec_load<N * N>(crec, st, CRec::PDN, P);
     SS_LOAD_FENCE();
 
     double dir_conv[D];   // dir_below - dir_above (new)
@@ -362,38 +383,20 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
     }
     double refl_dir[N], t3[N];
     mat_vec<N, D>(DAB, dir_above, refl_dir);
-    mat_vec<N, D>(SDN, dir_below, t3);
+    mat_vec<N, D>(Q, dir_below, t3);
 
-    // ---- issue group 4 (R), work on group 3 ----
-    double R[N * N];
-    rec_load<N * N>(lrec, st, LRec::R, R);
-    SS_LOAD_FENCE();
-
-    double rhs[N];
-    mat_vec<N, N>(T, diff_below, rhs);
-
-    // ---- issue group 5 (LU of the denominator), work on group 4 ----
-    double DEN[N * N];
-    rec_load<N * N>(crec, st, CRec::DEN, DEN);
-    SS_LOAD_FENCE();
-
-    {
-      double t2[N];
-      mat_vec<N, N>(R, refl_dir, t2);
-      SS_UNROLL_N(N)
-      for (int i = 0; i < N; ++i) rhs[i] = rhs[i] + t2[i] + t3[i];
-    }
-
-    // ---- issue group 6 (a_above, int_dir), work on group 5 ----
+    // ---- issue group 4 (a_above, int_dir), work on group 3 ----
     double AAB[N * N], IDIR[D * D];
     rec_load<N * N>(crec, st, CRec::AAB, AAB);
     rec_load<D * D>(lrec, st, LRec::IDIR, IDIR);
     SS_LOAD_FENCE();
 
-    lu_solve<N>(DEN, rhs);
-    vec_copy<N>(rhs, diff_above);
+    // flux at the base of the layer: diff = P diff_top + Q dir_top
+    mat_vec<N, N>(P, diff_below, diff_above);
+    SS_UNROLL_N(N)
+    for (int i = 0; i < N; ++i) diff_above[i] = diff_above[i] + t3[i];
 
-    // ---- issue group 7 (int_diff), work on group 6 ----
+    // ---- issue group 5 (int_diff), work on group 4 ----
     double IDIFF[N * N];
     rec_load<N * N>(lrec, st, LRec::IDIFF, IDIFF);
     SS_LOAD_FENCE();
@@ -423,7 +426,7 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
     SS_UNROLL_N(N)
     for (int i = 0; i < N; ++i) conv[i] = diff_below[i] - diff_above[i] - up_below[i] + up_above[i];
 
-    // ---- issue group 8 (int_dir_diff) and group 1 of the next layer down, work on group 7 ----
+    // ---- issue group 6 (int_dir_diff) and group 1 of the next layer down, work on group 5 ----
     double IDD[N * D];
     rec_load<N * D>(lrec, st, LRec::IDD, IDD);
     if (jlay > 0) {

@@ -137,6 +137,7 @@ struct Launch {
   int nspec;             // spectral bands (nsw or nlw)
   int ncu;               // column units = ncols * nspec
   int maxlay;            // largest nlay in the chunk
+  int lay_nelem, col_nelem;   // record sizes the plan sized the scratch for (checked at launch)
   double* lay;           // layer-matrix scratch  [tile][layer][elem pair][lane][2]
   double* col;           // adding-method scratch, same tiling
   double* top1;          // bc_out: sw_albedo / lw_emissivity   (nspec, ncol)

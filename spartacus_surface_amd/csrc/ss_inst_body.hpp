@@ -1,6 +1,9 @@
 // ss_inst_body.hpp - body shared by the inst_*.hip units.  The including file
 // defines SS_INST_URBAN (true/false), SS_INST_NREG (1..3), SS_INST_LW (0/1)
 // and SS_INST_NAME (launcher symbol).
+#include <cstdio>
+#include <cstdlib>
+
 #include "ss_kernels.hpp"
 #include "ss_column_lw.hpp"
 #include "ss_column_sw.hpp"
@@ -37,6 +40,15 @@ __global__ void __launch_bounds__(kBlock, SS_MIN_WAVES_COLUMN) k_column(const La
   else column_up_sw<U, R, NS>(L, cu);
 }
 
+// layer matrices + upward sweep of a whole column on one lane
+template <bool U, int R, int NS, bool LW>
+__global__ void __launch_bounds__(kBlock, 1) k_layer_up(const Launch L) {
+  const int cu = blockIdx.x * kBlock + threadIdx.x;
+  if (cu >= L.ncu) return;
+  if (LW) column_up_lw<U, R, NS, true>(L, cu);
+  else column_up_sw<U, R, NS, true>(L, cu);
+}
+
 // downward flux sweep: vectors only, several waves per SIMD
 template <bool U, int R, int NS, bool LW>
 __global__ void __launch_bounds__(kBlock, SS_MIN_WAVES_DOWN) k_down(const Launch L) {
@@ -49,13 +61,30 @@ __global__ void __launch_bounds__(kBlock, SS_MIN_WAVES_DOWN) k_down(const Launch
 
 template <int NS>
 void launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev) {
+  {
+    // the plan sized the scratch with its own formula: it must match the records
+    constexpr int N = SS_INST_NREG * NS, D = SS_INST_NREG;
+    constexpr int lay_ne = SS_INST_LW ? LwRec<N>::NELEM : SwRec<N, D>::NELEM;
+    constexpr int col_ne = SS_INST_LW ? LwColRec<N>::NELEM : SwColRec<N, D>::NELEM;
+    if (L.lay_nelem != lay_ne || L.col_nelem != col_ne) {
+      fprintf(stderr, "spartacus_surface_hip: scratch record size mismatch (%d/%d vs %d/%d)\n",
+              L.lay_nelem, L.col_nelem, lay_ne, col_ne);
+      abort();
+    }
+  }
   const unsigned gx = (unsigned)((L.ncu + kBlock - 1) / kBlock);
   if (ev) hipEventRecord(ev[0], stream);
+#ifdef SS_FUSED_UP
+  hipLaunchKernelGGL((k_layer_up<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx), dim3(kBlock), 0,
+                     stream, L);
+  if (ev) hipEventRecord(ev[1], stream);
+#else
   hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx, (unsigned)L.maxlay),
                      dim3(kBlock), 0, stream, L);
   if (ev) hipEventRecord(ev[1], stream);
   hipLaunchKernelGGL((k_column<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx), dim3(kBlock), 0,
                      stream, L);
+#endif
   if (ev) hipEventRecord(ev[2], stream);
   {
     const unsigned gd = (unsigned)((2L * L.ncu + kBlock - 1) / kBlock);

@@ -72,9 +72,9 @@ inline int lay_nelem(bool lw, const ClassKey& k) {
 }
 inline int col_nelem(bool lw, const ClassKey& k) {
   const int n = k.nreg * k.ns, d = k.nreg;
-  // LW: a_above, LU(den), a_below + 3 vectors; SW: a_above, d_above, LU(den), a_below, d_below
+  // = LwColRec<n>::NELEM / SwColRec<n,d>::NELEM (ss_column_lw.hpp, ss_column_sw.hpp)
   auto ev = [](int x) { return (x + 1) & ~1; };
-  return lw ? 3 * ev(n * n) + 3 * ev(n) : 3 * ev(n * n) + 2 * ev(n * d);
+  return lw ? 3 * ev(n * n) + 3 * ev(n) : 3 * ev(n * n) + 3 * ev(n * d);
 }
 
 // Runtime (urban, nreg, ns) -> template instance
@@ -121,9 +121,16 @@ class Plan {
   size_t flat_off = 0, night_off = 0;
   size_t index_elems = 0;
 
-  double* d_lay = nullptr;
-  double* d_col = nullptr;
+  // Scratch of the layer / adding-method records, one set per "pipe": successive
+  // chunks (and the SW and LW families) alternate between the pipes, which the
+  // backend maps to concurrent streams, so that the memory-bound column kernels
+  // of one chunk overlap with the arithmetic-bound layer kernel of the next.
+  static constexpr int kMaxPipes = 2;
+  int npipes = 1;
+  double* d_lay[kMaxPipes] = {nullptr, nullptr};
+  double* d_col[kMaxPipes] = {nullptr, nullptr};
   size_t scratch_budget_bytes = 0;
+  int pipes_wanted = kMaxPipes;
   size_t lay_bytes = 0, col_bytes = 0;
   unsigned long long* d_eigen_fail = nullptr;
 
@@ -137,10 +144,14 @@ class Plan {
     dev.clear();
     dev_elems.clear();
     if (d_index) Backend::free(d_index);
-    if (d_lay) Backend::free(d_lay);
-    if (d_col) Backend::free(d_col);
+    for (int p = 0; p < kMaxPipes; ++p) {
+      if (d_lay[p]) Backend::free(d_lay[p]);
+      if (d_col[p]) Backend::free(d_col[p]);
+      d_lay[p] = d_col[p] = nullptr;
+    }
+    lay_bytes = col_bytes = 0;
     if (d_eigen_fail) Backend::free(d_eigen_fail);
-    d_index = nullptr; d_lay = d_col = nullptr; d_eigen_fail = nullptr;
+    d_index = nullptr; d_eigen_fail = nullptr;
     timers.release();
   }
 
@@ -236,6 +247,8 @@ class Plan {
     if (cfg.do_lw && (!lw || lw->nspec != nlw)) { error = "lw spectral properties missing / nspec mismatch"; return SS_ERR_BAD_ARGUMENT; }
     const char* mb = std::getenv("SPARTACUS_SCRATCH_MB");
     scratch_budget_bytes = (mb ? (size_t)std::atol(mb) : (size_t)4096) << 20;
+    const char* np = std::getenv("SPARTACUS_PIPES");
+    pipes_wanted = np ? std::max(1, std::atoi(np)) : kMaxPipes;
 
     ensure("bc_out.sw_albedo", std::max<size_t>(1, (size_t)nsw * ncol));
     ensure("bc_out.sw_albedo_dir", std::max<size_t>(1, (size_t)nsw * ncol));
@@ -390,8 +403,37 @@ class Plan {
     };
     account(sw_classes, false, nsw);
     account(lw_classes, true, nlw);
-    if (need_lay > lay_bytes) { if (d_lay) Backend::free(d_lay); d_lay = static_cast<double*>(Backend::alloc(need_lay)); lay_bytes = need_lay; }
-    if (need_col > col_bytes) { if (d_col) Backend::free(d_col); d_col = static_cast<double*>(Backend::alloc(need_col)); col_bytes = need_col; }
+    // a second pipe only pays off when there is more than one launch to overlap
+    size_t nlaunch = 0;
+    for (auto& c : sw_classes) nlaunch += (c.cols.size() + chunk_columns(c, false, nsw) - 1) / chunk_columns(c, false, nsw);
+    for (auto& c : lw_classes) nlaunch += (c.cols.size() + chunk_columns(c, true, nlw) - 1) / chunk_columns(c, true, nlw);
+    npipes = std::max(1, std::min<int>({kMaxPipes, pipes_wanted, (int)nlaunch}));
+    if (need_lay > lay_bytes || need_col > col_bytes) {
+      for (int p = 0; p < kMaxPipes; ++p) {
+        if (d_lay[p]) Backend::free(d_lay[p]);
+        if (d_col[p]) Backend::free(d_col[p]);
+        d_lay[p] = d_col[p] = nullptr;
+      }
+      lay_bytes = std::max(lay_bytes, need_lay);
+      col_bytes = std::max(col_bytes, need_col);
+    }
+    for (int p = 0; p < npipes; ++p) {
+      if (!d_lay[p]) d_lay[p] = static_cast<double*>(Backend::alloc(lay_bytes));
+      if (!d_col[p]) d_col[p] = static_cast<double*>(Backend::alloc(col_bytes));
+    }
+    return SS_OK;
+  }
+
+  int set_pipes(int n) {
+    pipes_wanted = std::max(1, std::min(n, (int)kMaxPipes));
+    npipes = std::min(npipes, pipes_wanted);
+    if (pipes_wanted > npipes && lay_bytes) {
+      for (int p = npipes; p < pipes_wanted; ++p) {
+        if (!d_lay[p]) d_lay[p] = static_cast<double*>(Backend::alloc(lay_bytes));
+        if (!d_col[p]) d_col[p] = static_cast<double*>(Backend::alloc(col_bytes));
+      }
+      npipes = pipes_wanted;
+    }
     return SS_OK;
   }
 
@@ -488,7 +530,8 @@ class Plan {
     return ok ? SS_OK : SS_ERR_BAD_ARGUMENT;
   }
 
-  Launch make_launch(const ColumnClass& c, bool lw, size_t first, size_t count, int chunk_maxlay) const {
+  Launch make_launch(const ColumnClass& c, bool lw, size_t first, size_t count, int chunk_maxlay,
+                     int pipe) const {
     Launch L;
     L.in = make_inputs(lw);
     const bool urban = c.key.urban;
@@ -506,8 +549,10 @@ class Plan {
     L.nspec = lw ? nlw : nsw;
     L.ncu = L.ncols * L.nspec;
     L.maxlay = chunk_maxlay;
-    L.lay = d_lay;
-    L.col = d_col;
+    L.lay_nelem = lay_nelem(lw, c.key);
+    L.col_nelem = col_nelem(lw, c.key);
+    L.lay = d_lay[pipe];
+    L.col = d_col[pipe];
     L.top1 = darr(lw ? "bc_out.lw_emissivity" : "bc_out.sw_albedo");
     L.top2 = darr(lw ? "bc_out.lw_emission" : "bc_out.sw_albedo_dir");
     L.flux_a = flux_dev(lw ? "lw_internal" : "sw_norm_dir");
@@ -544,6 +589,8 @@ class Plan {
       Backend::launch_flat(make_misc(flat_off, flat_cols.size()), timers);
     }
     if (!night_cols.empty()) Backend::launch_night(make_misc(night_off, night_cols.size()), timers);
+    Backend::fork(npipes);
+    int nlaunched = 0;
     for (int lw = 0; lw < 2; ++lw) {
       const auto& classes = lw ? lw_classes : sw_classes;
       const int nspec = lw ? nlw : nsw;
@@ -554,11 +601,13 @@ class Plan {
         for (size_t first = 0; first < c.cols.size(); first += chunk) {
           const size_t count = std::min(chunk, c.cols.size() - first);
           const int chunk_maxlay = h_nlay[c.cols[first]];   // sorted descending
-          Launch L = make_launch(c, lw != 0, first, count, chunk_maxlay);
-          Backend::launch_solver(c.key, lw != 0, L, timers);
+          const int pipe = nlaunched++ % npipes;
+          Launch L = make_launch(c, lw != 0, first, count, chunk_maxlay, pipe);
+          Backend::launch_solver(c.key, lw != 0, L, timers, pipe);
         }
       }
     }
+    Backend::join(npipes);
     timers.end_solve();
     return SS_OK;
   }

@@ -35,7 +35,7 @@ STATUS = {
 EXPORTS = (
     "spartacus_radsurf_hip", "ss_plan_create", "ss_plan_upload",
     "ss_plan_calc_simple_spectrum_lw", "ss_plan_solve", "ss_plan_synchronize",
-    "ss_plan_download", "ss_plan_last_kernel_ms", "ss_plan_eigen_failures",
+    "ss_plan_download", "ss_plan_last_kernel_ms", "ss_plan_eigen_failures", "ss_plan_set_pipes",
     "ss_plan_device_ptr", "ss_plan_destroy", "ss_device_count", "ss_set_device",
     "ss_last_error", "ss_version",
 )
@@ -149,6 +149,10 @@ class Plan:
         ms = C.c_double(0.0)
         _check(self._lib.ss_plan_last_kernel_ms(self._h, name.encode(), C.byref(ms)))
         return ms.value
+
+    def set_pipes(self, npipes):
+        """Concurrent streams used by solve(): 1 = serial kernels, 2 = overlapped chunks."""
+        _check(self._lib.ss_plan_set_pipes(self._h, C.c_int32(int(npipes))))
 
     def eigen_failures(self):
         n = C.c_int64(0)

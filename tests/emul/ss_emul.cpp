@@ -54,7 +54,9 @@ struct EmulBackend {
       else ss::column_unit_sw<U, R, NS>(L, cu);
     }
   }
-  static void launch_solver(const ss::ClassKey& key, bool lw, const ss::Launch& L, Timers&) {
+  static void fork(int) {}
+  static void join(int) {}
+  static void launch_solver(const ss::ClassKey& key, bool lw, const ss::Launch& L, Timers&, int) {
 #define EMUL_CALL(U, R, NS) run<U, R, NS>(lw, L)
     SS_DISPATCH(key, EMUL_CALL);
 #undef EMUL_CALL
