@@ -109,6 +109,34 @@ def measured_traffic(family, cols_per_launch, workload="c3"):
         return None, None
 
 
+def scale_sum_rate(plan, case, ncol):
+    """SURVEY 8f row 1 on the device: canopy_flux%scale / %sum over the resident
+    results (one streaming kernel, HBM-bound); returns its HIP-event time and the
+    bytes it has to move (reads + writes of every member touched)."""
+    from spartacus_surface_amd import abi, types
+    cfg, cp = case["config"], case["canopy"]
+    plan.solve()
+    plan.scale_and_sum(case.get("top_flux_dn_sw"), case.get("top_flux_dn_direct_sw"),
+                       case.get("top_flux_dn_lw"))
+    plan.synchronize()
+    ms = plan.kernel_ms("misc")
+    nbytes = 0
+    for nspec, direct, scaled_a, on in ((cfg.nsw, True, 1, cfg.do_sw), (cfg.nlw, False, 0, cfg.do_lw)):
+        if not on:
+            continue
+        f = types.CanopyFlux()
+        f.allocate(cfg, 1, 1, nspec, use_direct=direct, do_save_flux_profile=False)
+        for n, kind in abi.FLUX_FIELDS:
+            if getattr(f, n) is None:
+                continue
+            per = {"sc": nspec * cp.ncol, "sl": nspec * cp.ntotlay, "c": cp.ncol, "l": cp.ntotlay}[kind]
+            writes = 1 + ((scaled_a + 1) if kind in ("sc", "sl") else 0)
+            nbytes += 8 * per * (2 + writes)
+    return {"ms": ms, "bytes": nbytes, "GB/s": nbytes / (ms * 1e-3) / 1e9 if ms > 0 else None,
+            "hbm_frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None,
+            "note": "canopy_flux%scale + %sum of all four flux objects on the device (next row f1)"}
+
+
 def host_entry_rate(ncol):
     """PCIe-inclusive rate of the host entry point (spartacus_radsurf_hip: host
     buffers in, host buffers out, one call for all columns) on a bounded sample.
@@ -150,6 +178,10 @@ def main():
                     help="c3 (default) is the headline configuration; the others are extra lines")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="timed region only: no serial-kernel steps, no CPU baseline, no PCIe sample "
+                         "(what the rocprofv3 kernel-trace run uses, so that its per-kernel averages "
+                         "are those of the timed region)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -218,7 +250,7 @@ def main():
     # durations without the chunk overlap of the timed region
     pipes = int(os.environ.get("SPARTACUS_PIPES", "2"))
     serial_ms = None
-    if pipes > 1:
+    if pipes > 1 and not args.no_extras:
         plan.set_pipes(1)
         serial_ms = {k: 0.0 for k in fam_ms}
         serial_n = dict.fromkeys(fam_ms, 0)
@@ -280,7 +312,9 @@ def main():
                 "traffic": measured_traffic(sd, s_cols, args.workload)[0],
                 "fp64_tflops": fpc * args.columns / (s_tot * 1e-3) / 1e12,
                 "fp64_frac": fpc * args.columns / (s_tot * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_extras and case.get("top_flux_dn_sw") is not None:
+            line["scale_sum"] = scale_sum_rate(plan, case, args.columns)
+        if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             line["cpu_baseline"] = cpu_baseline(args.workload, min(args.cpu_sample, args.columns))
             line["pcie_inclusive"] = host_entry_rate(min(args.columns, 200_000))
         print(json.dumps(line), flush=True)

@@ -267,6 +267,22 @@ int ss_plan_last_kernel_ms(ss_plan *plan, const char *name, double *ms);
  * in the last solve (the reference silently ignores these:
  * radtool_eigen_decomposition.F90:498-510, calc_matrices_sw_eig.F90:183). */
 int ss_plan_eigen_failures(ss_plan *plan, int64_t *count);
+/* canopy_flux%scale and %sum (radsurf/radsurf_canopy_flux.F90:212-282, 399-460)
+ * exactly as the offline driver applies them after radsurf
+ * (driver/spartacus_surface_driver.F90:250-261), on the device-resident results
+ * of the last ss_plan_solve, for the plan's column range:
+ *     sw_norm_dir  *= top_flux_dn_direct_sw
+ *     sw_norm_diff *= top_flux_dn_sw - top_flux_dn_direct_sw
+ *     sw_flux       = sw_norm_dir + sw_norm_diff
+ *     lw_norm      *= top_flux_dn_lw
+ *     lw_flux       = lw_internal + lw_norm
+ * The factors are host arrays (nsw, ncol) / (nlw, ncol); sunlit fractions are
+ * not scaled.  A later ss_plan_download returns the scaled objects,
+ * ss_plan_download_sums the two sums (members laid out like any ss_flux). */
+int ss_plan_scale_and_sum(ss_plan *plan, const double *top_flux_dn_sw,
+                          const double *top_flux_dn_direct_sw,
+                          const double *top_flux_dn_lw);
+int ss_plan_download_sums(ss_plan *plan, ss_flux *sw_flux, ss_flux *lw_flux);
 /* Number of concurrent HIP streams ("pipes") the next ss_plan_solve spreads its
  * chunk launches over: 1 = strictly serial kernels (what per-kernel profiling
  * wants), 2 (default, env SPARTACUS_PIPES) = the memory-bound column kernels of

@@ -1,5 +1,6 @@
-﻿!mod$ v1 sum:ca77e565b532d64c
+﻿!mod$ v1 sum:dde65d117102be91
 !need$ a7fbb53af6e3c6a5 n ref_harness_types
+!need$ bb381bf46e508468 i __fortran_builtins
 !need$ 0bde2ac47243ead2 i iso_c_binding
 module ref_harness
 use ref_harness_types,only:ss_max_streams
@@ -90,6 +91,8 @@ use,intrinsic::iso_c_binding,only:c_uint_least32_t
 use,intrinsic::iso_c_binding,only:c_uint_least64_t
 use,intrinsic::iso_c_binding,only:c_uint_least128_t
 use,intrinsic::iso_c_binding,only:c_f_procpointer
+use,intrinsic::__fortran_builtins,only:iso_c_binding$__fortran_builtins$c_associated_c_ptr=>c_associated_c_ptr
+private::iso_c_binding$__fortran_builtins$c_associated_c_ptr
 contains
 subroutine fill_config(cc,config)
 use radsurf_config,only:config_type
@@ -101,7 +104,7 @@ use radsurf_canopy_flux,only:canopy_flux_type
 type(canopy_flux_type),intent(in)::f
 type(ss_flux),intent(in)::cf
 end
-function spartacus_radsurf_ref(cc,ccan,csw,clw,cbc,istartcol_in,iendcol_in,c_sw_dir,c_sw_diff,c_lw_int,c_lw_norm,nblocksize,nrepeat,do_simple_spectrum,want_profiles,elapsed) bind(c,name="spartacus_radsurf_ref") result(istatus)
+function spartacus_radsurf_ref(cc,ccan,csw,clw,cbc,istartcol_in,iendcol_in,c_sw_dir,c_sw_diff,c_lw_int,c_lw_norm,nblocksize,nrepeat,do_simple_spectrum,want_profiles,elapsed,p_top_sw,p_top_sw_dir,p_top_lw,p_sw_flux,p_lw_flux) bind(c,name="spartacus_radsurf_ref") result(istatus)
 type(ss_config),intent(in)::cc
 type(ss_canopy),intent(in)::ccan
 type(ss_sw_spectral),intent(in)::csw
@@ -118,6 +121,11 @@ integer(4),value::nrepeat
 integer(4),value::do_simple_spectrum
 integer(4),value::want_profiles
 real(8),intent(out)::elapsed
+type(c_ptr),value::p_top_sw
+type(c_ptr),value::p_top_sw_dir
+type(c_ptr),value::p_top_lw
+type(c_ptr),value::p_sw_flux
+type(c_ptr),value::p_lw_flux
 integer(4)::istatus
 end
 subroutine ref_legendre_gauss(nstream,clg) bind(c,name="ref_legendre_gauss")

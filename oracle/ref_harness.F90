@@ -251,7 +251,8 @@ contains
   ! want_profiles selects the optional flux-profile arrays of canopy_flux.
   function spartacus_radsurf_ref(cc, ccan, csw, clw, cbc, istartcol_in, iendcol_in, &
        &  c_sw_dir, c_sw_diff, c_lw_int, c_lw_norm, &
-       &  nblocksize, nrepeat, do_simple_spectrum, want_profiles, elapsed) &
+       &  nblocksize, nrepeat, do_simple_spectrum, want_profiles, elapsed, &
+       &  p_top_sw, p_top_sw_dir, p_top_lw, p_sw_flux, p_lw_flux) &
        &  bind(c, name=HARNESS_ENTRY) result(istatus)
 
     use omp_lib
@@ -273,7 +274,14 @@ contains
     type(ss_flux), intent(in) :: c_sw_dir, c_sw_diff, c_lw_int, c_lw_norm
     integer(c_int32_t), value :: nblocksize, nrepeat, do_simple_spectrum, want_profiles
     real(c_double), intent(out) :: elapsed
+    ! Optional post-processing of the driver (spartacus_surface_driver.F90:250-261):
+    ! non-null top-of-canopy fluxes (nsw,ncol)/(nlw,ncol) => canopy_flux%scale and
+    ! %sum are applied; the scaled objects and the two sums are returned.
+    type(c_ptr), value :: p_top_sw, p_top_sw_dir, p_top_lw, p_sw_flux, p_lw_flux
     integer(c_int) :: istatus
+    real(c_double), allocatable :: top_sw(:,:), top_sw_dir(:,:), top_lw(:,:)
+    type(canopy_flux_type) :: sw_flux, lw_flux
+    type(ss_flux), pointer :: c_sw_flux, c_lw_flux
 
     type(config_type)                 :: config
     type(canopy_properties_type)      :: canopy_props
@@ -382,6 +390,28 @@ contains
     end do
     tstop = omp_get_wtime()
     elapsed = tstop - tstart
+
+    if (config%do_sw .and. c_associated(p_top_sw) .and. c_associated(p_top_sw_dir) &
+         &  .and. c_associated(p_sw_flux)) then
+      call get_r2(p_top_sw, nsw, ncol, top_sw)
+      call get_r2(p_top_sw_dir, nsw, ncol, top_sw_dir)
+      call sw_flux%allocate(config, ncol, ntotlay, config%nsw, use_direct=.true., &
+           &  do_save_flux_profile=(want_profiles /= 0))
+      call sw_norm_dir%scale(canopy_props%nlay, top_sw_dir)
+      call sw_norm_diff%scale(canopy_props%nlay, top_sw - top_sw_dir)
+      call sw_flux%sum(sw_norm_dir, sw_norm_diff)
+      call c_f_pointer(p_sw_flux, c_sw_flux)
+      call copy_flux_out(sw_flux, c_sw_flux)
+    end if
+    if (config%do_lw .and. c_associated(p_top_lw) .and. c_associated(p_lw_flux)) then
+      call get_r2(p_top_lw, nlw, ncol, top_lw)
+      call lw_flux%allocate(config, ncol, ntotlay, config%nlw, use_direct=.false., &
+           &  do_save_flux_profile=(want_profiles /= 0))
+      call lw_norm%scale(canopy_props%nlay, top_lw)
+      call lw_flux%sum(lw_internal, lw_norm)
+      call c_f_pointer(p_lw_flux, c_lw_flux)
+      call copy_flux_out(lw_flux, c_lw_flux)
+    end if
 
     call put_r2(bc_out%sw_albedo, cbc%sw_albedo, config%nsw, ncol)
     call put_r2(bc_out%sw_albedo_dir, cbc%sw_albedo_dir, config%nsw, ncol)

@@ -42,9 +42,9 @@ hipStream_t stream() {
 
 // Worker streams of the solve ("pipes" of ss_plan_impl.hpp): pipe 0 is the
 // library's main stream, further pipes fork from it and join it again.
-constexpr int kMaxPipes = 2;
-hipStream_t g_pipe[kMaxPipes] = {nullptr, nullptr};
-hipEvent_t g_fork_ev = nullptr, g_join_ev[kMaxPipes] = {nullptr, nullptr};
+constexpr int kMaxPipes = 4;
+hipStream_t g_pipe[kMaxPipes] = {};
+hipEvent_t g_fork_ev = nullptr, g_join_ev[kMaxPipes] = {};
 
 hipStream_t pipe_stream(int p) {
   if (p <= 0) return stream();
@@ -71,6 +71,15 @@ __global__ void __launch_bounds__(256) k_spectrum_col(const ss::SpectrumLaunch S
 __global__ void __launch_bounds__(256) k_spectrum_lay(const ss::SpectrumLaunch S) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < S.nlays) ss::spectrum_lay_unit(S, i);
+}
+
+__global__ void __launch_bounds__(256) k_scale_sum(const ss::ScaleSumLaunch S) {
+  // blockIdx.y = member kind (ss::scale_sum_unit)
+  const int kind = blockIdx.y;
+  const long n = kind == 0 ? (long)S.nspec * S.ncols : kind == 1 ? (long)S.nspec * S.nlays
+               : kind == 2 ? S.ncols : S.nlays;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    ss::scale_sum_unit(S, kind, i);
 }
 
 enum Family { FAM_SW_LAYER = 0, FAM_SW_COLUMN, FAM_LW_LAYER, FAM_LW_COLUMN, FAM_MISC, FAM_SW_DOWN, FAM_LW_DOWN, FAM_COUNT };
@@ -167,6 +176,16 @@ struct HipBackend {
     hipEvent_t a = t.next(), b = t.next();
     hipEventRecord(a, stream());
     hipLaunchKernelGGL(k_night, dim3((M.ncols + 255) / 256), dim3(256), 0, stream(), M);
+    hipEventRecord(b, stream());
+    t.spans.push_back({FAM_MISC, a, b});
+  }
+  static void launch_scale_sum(const ss::ScaleSumLaunch& S, Timers& t) {
+    const long nmax = (long)S.nspec * std::max(S.ncols, S.nlays);
+    if (nmax <= 0) return;
+    const unsigned gx = (unsigned)std::min<long>((nmax + 255) / 256, 1L << 20);
+    hipEvent_t a = t.next(), b = t.next();
+    hipEventRecord(a, stream());
+    hipLaunchKernelGGL(k_scale_sum, dim3(gx, 4), dim3(256), 0, stream(), S);
     hipEventRecord(b, stream());
     t.spans.push_back({FAM_MISC, a, b});
   }
@@ -345,6 +364,21 @@ int ss_plan_last_kernel_ms(ss_plan* plan, const char* name, double* ms) {
 int ss_plan_eigen_failures(ss_plan* plan, int64_t* count) {
   if (!plan || !count) return SS_ERR_BAD_ARGUMENT;
   return guarded([&]() { *count = plan->impl.eigen_failures(); return (int)SS_OK; });
+}
+
+int ss_plan_scale_and_sum(ss_plan* plan, const double* top_flux_dn_sw, const double* top_flux_dn_direct_sw,
+                          const double* top_flux_dn_lw) {
+  if (!plan) return SS_ERR_BAD_ARGUMENT;
+  return guarded([&]() {
+    int rc = plan->impl.scale_and_sum(top_flux_dn_sw, top_flux_dn_direct_sw, top_flux_dn_lw);
+    if (rc) g_last_error = plan->impl.error;
+    return rc;
+  });
+}
+
+int ss_plan_download_sums(ss_plan* plan, ss_flux* sw_flux, ss_flux* lw_flux) {
+  if (!plan) return SS_ERR_BAD_ARGUMENT;
+  return guarded([&]() { return plan->impl.download_sums(sw_flux, lw_flux); });
 }
 
 int ss_plan_set_pipes(ss_plan* plan, int32_t npipes) {

@@ -107,6 +107,61 @@ SS_HD void zero_unit(const Inputs& in, const FluxDev& f, int nspec, int col) {
   }
 }
 
+// ---- canopy_flux%scale + %sum (radsurf_canopy_flux.F90:212-282, 399-460) as
+// the driver applies them after radsurf (spartacus_surface_driver.F90:250-261):
+//   a = fa * a,  b = fb * b  (in place; sunlit fractions are not scaled),
+//   sum = a + b   (a member missing in an operand counts as zero).
+struct ScaleSumLaunch {
+  FluxDev a, b, sum;
+  const double* fa;        // (nspec, ncol) factor of a, nullptr = a is not scaled
+  const double* fb;        // (nspec, ncol) factor of b, nullptr = b is not scaled
+  const int32_t* indcol;   // (ntotlay) 0-based column of every packed layer
+  int nspec;
+  long col0, ncols;        // column range (0-based first, count)
+  long lay0, nlays;        // packed layer range
+};
+
+// kind 0: one (band, column) element of every (nspec, ncol) member;
+// kind 1: one (band, layer) element of every (nspec, ntotlay) member;
+// kind 2 / 3: one column / layer of the unscaled (ncol) / (ntotlay) members
+SS_HD void scale_sum_unit(const ScaleSumLaunch& S, int kind, long i) {
+#if defined(__clang__)
+#pragma clang fp contract(off)   // the reference rounds the product before the sum
+#endif
+  long idx, fidx = 0;
+  if (kind == 0) {
+    idx = (long)S.nspec * S.col0 + i;
+    fidx = idx;
+  } else if (kind == 1) {
+    idx = (long)S.nspec * S.lay0 + i;
+    const long lay = idx / S.nspec, spec = idx - lay * S.nspec;
+    fidx = spec + (long)S.nspec * S.indcol[lay];
+  } else if (kind == 2) {
+    idx = S.col0 + i;
+  } else {
+    idx = S.lay0 + i;
+  }
+  const bool scaled = (kind <= 1);
+  const double fa = (scaled && S.fa) ? S.fa[fidx] : 1.0;
+  const double fb = (scaled && S.fb) ? S.fb[fidx] : 1.0;
+  for (int F = 0; F < F_NFIELDS; ++F) {
+    if (flux_field_shape(F) != kind) continue;
+    double* pa = S.a.f[F];
+    double* pb = S.b.f[F];
+    double* ps = S.sum.f[F];
+    double va = 0.0, vb = 0.0;
+    if (pa) {
+      va = pa[idx];
+      if (scaled && S.fa) { va = fa * va; pa[idx] = va; }
+    }
+    if (pb) {
+      vb = pb[idx];
+      if (scaled && S.fb) { vb = fb * vb; pb[idx] = vb; }
+    }
+    if (ps) ps[idx] = va + vb;
+  }
+}
+
 // calc_simple_spectrum_lw: per-column and per-layer parts
 struct SpectrumLaunch {
   const double* ground_temperature;

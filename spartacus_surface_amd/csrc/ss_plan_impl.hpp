@@ -117,6 +117,7 @@ class Plan {
 
   std::vector<ColumnClass> sw_classes, lw_classes;
   std::vector<int32_t> flat_cols, night_cols, lwzero_urban_cols;
+  std::vector<int32_t> h_indcol;
   int32_t* d_index = nullptr;
   size_t flat_off = 0, night_off = 0;
   size_t index_elems = 0;
@@ -125,12 +126,13 @@ class Plan {
   // chunks (and the SW and LW families) alternate between the pipes, which the
   // backend maps to concurrent streams, so that the memory-bound column kernels
   // of one chunk overlap with the arithmetic-bound layer kernel of the next.
-  static constexpr int kMaxPipes = 2;
+  static constexpr int kMaxPipes = 4;
   int npipes = 1;
-  double* d_lay[kMaxPipes] = {nullptr, nullptr};
-  double* d_col[kMaxPipes] = {nullptr, nullptr};
+  double* d_lay[kMaxPipes] = {};
+  double* d_col[kMaxPipes] = {};
   size_t scratch_budget_bytes = 0;
-  int pipes_wanted = kMaxPipes;
+  static constexpr int kDefaultPipes = 2;
+  int pipes_wanted = kDefaultPipes;
   size_t lay_bytes = 0, col_bytes = 0;
   unsigned long long* d_eigen_fail = nullptr;
 
@@ -248,7 +250,7 @@ class Plan {
     const char* mb = std::getenv("SPARTACUS_SCRATCH_MB");
     scratch_budget_bytes = (mb ? (size_t)std::atol(mb) : (size_t)4096) << 20;
     const char* np = std::getenv("SPARTACUS_PIPES");
-    pipes_wanted = np ? std::max(1, std::atoi(np)) : kMaxPipes;
+    pipes_wanted = np ? std::max(1, std::atoi(np)) : kDefaultPipes;
 
     ensure("bc_out.sw_albedo", std::max<size_t>(1, (size_t)nsw * ncol));
     ensure("bc_out.sw_albedo_dir", std::max<size_t>(1, (size_t)nsw * ncol));
@@ -265,6 +267,7 @@ class Plan {
   int upload(const ss_canopy* can, const ss_sw_spectral* sw, const ss_lw_spectral* lw) {
     if (can->ncol != ncol || can->ntotlay != ntotlay) { error = "shape changed since plan creation"; return SS_ERR_BAD_ARGUMENT; }
     h_nlay.assign(can->nlay, can->nlay + ncol);
+    h_indcol.clear();
     h_istartlay.assign(can->istartlay, can->istartlay + ncol);
     h_irep.assign(can->i_representation, can->i_representation + ncol);
     if (can->cos_sza) h_cos_sza.assign(can->cos_sza, can->cos_sza + ncol);
@@ -709,6 +712,57 @@ class Plan {
     }
     if (cfg.do_sw) { xfer_flux("sw_norm_dir", sw_dir, nsw, false); xfer_flux("sw_norm_diff", sw_diff, nsw, false); }
     if (cfg.do_lw) { xfer_flux("lw_internal", lw_int, nlw, false); xfer_flux("lw_norm", lw_nrm, nlw, false); }
+    return SS_OK;
+  }
+
+  // ---- canopy_flux%scale + %sum on the device-resident results ----
+  // top_flux_dn_sw, top_flux_dn_direct_sw: (nsw, ncol); top_flux_dn_lw: (nlw, ncol)
+  // (driver/spartacus_surface_driver.F90:250-261).  Works on the plan's column range.
+  int scale_and_sum(const double* top_sw, const double* top_sw_dir, const double* top_lw) {
+    if (iendcol < istartcol) return SS_OK;
+    if (h_indcol.size() != (size_t)ntotlay) {
+      h_indcol.assign(std::max(1, ntotlay), 0);
+      for (int c = 0; c < ncol; ++c)
+        for (int l = 0; l < h_nlay[c]; ++l) h_indcol[h_istartlay[c] - 1 + l] = c;
+      mirror("canopy.indcol", h_indcol.data(), h_indcol.size(), sizeof(int32_t));
+    }
+    auto launch = [&](const char* oa, const char* ob, const char* osum, const double* fa, const double* fb,
+                      int nspec, bool use_direct) {
+      alloc_flux(osum, nspec, use_direct);
+      ScaleSumLaunch S;
+      S.a = flux_dev(oa);
+      S.b = flux_dev(ob);
+      S.sum = flux_dev(osum);
+      S.fa = fa;
+      S.fb = fb;
+      S.indcol = static_cast<const int32_t*>(dev["canopy.indcol"]);
+      S.nspec = nspec;
+      S.col0 = istartcol - 1;
+      S.ncols = iendcol - istartcol + 1;
+      S.lay0 = lay_first;
+      S.nlays = lay_count;
+      Backend::launch_scale_sum(S, timers);
+    };
+    if (cfg.do_sw) {
+      if (!top_sw || !top_sw_dir) { error = "top-of-canopy shortwave fluxes missing"; return SS_ERR_BAD_ARGUMENT; }
+      const size_t n = (size_t)nsw * ncol;
+      std::vector<double> diff(n);
+      for (size_t k = 0; k < n; ++k) diff[k] = top_sw[k] - top_sw_dir[k];
+      mirror("factor.sw_dir", top_sw_dir, n);
+      mirror("factor.sw_diff", diff.data(), n);
+      launch("sw_norm_dir", "sw_norm_diff", "sw_flux", darr("factor.sw_dir"), darr("factor.sw_diff"), nsw, true);
+    }
+    if (cfg.do_lw) {
+      if (!top_lw) { error = "top-of-canopy longwave flux missing"; return SS_ERR_BAD_ARGUMENT; }
+      mirror("factor.lw", top_lw, (size_t)nlw * ncol);
+      launch("lw_internal", "lw_norm", "lw_flux", nullptr, darr("factor.lw"), nlw, false);
+    }
+    return SS_OK;
+  }
+  int download_sums(ss_flux* sw_flux, ss_flux* lw_flux) {
+    Backend::sync();
+    if (cfg.do_sw) xfer_flux("sw_flux", sw_flux, nsw, true);
+    if (cfg.do_lw) xfer_flux("lw_flux", lw_flux, nlw, true);
     return SS_OK;
   }
 

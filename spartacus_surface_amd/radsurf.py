@@ -18,6 +18,8 @@ or no MI355X is visible, these raise.
 import ctypes as C
 import os
 
+import numpy as np
+
 from . import abi
 
 # SPARTACUS_HIP_LIB selects another build of the SAME HIP library (kernel tuning
@@ -35,7 +37,7 @@ STATUS = {
 EXPORTS = (
     "spartacus_radsurf_hip", "ss_plan_create", "ss_plan_upload",
     "ss_plan_calc_simple_spectrum_lw", "ss_plan_solve", "ss_plan_synchronize",
-    "ss_plan_download", "ss_plan_last_kernel_ms", "ss_plan_eigen_failures", "ss_plan_set_pipes",
+    "ss_plan_download", "ss_plan_last_kernel_ms", "ss_plan_eigen_failures", "ss_plan_set_pipes", "ss_plan_scale_and_sum", "ss_plan_download_sums",
     "ss_plan_device_ptr", "ss_plan_destroy", "ss_device_count", "ss_set_device",
     "ss_last_error", "ss_version",
 )
@@ -149,6 +151,25 @@ class Plan:
         ms = C.c_double(0.0)
         _check(self._lib.ss_plan_last_kernel_ms(self._h, name.encode(), C.byref(ms)))
         return ms.value
+
+    def scale_and_sum(self, top_flux_dn_sw=None, top_flux_dn_direct_sw=None, top_flux_dn_lw=None):
+        """canopy_flux%scale / %sum on the device, as the reference's driver applies
+        them after radsurf (driver/spartacus_surface_driver.F90:250-261)."""
+        def ptr(a):
+            if a is None:
+                return None, None
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            return a, a.ctypes.data_as(C.POINTER(C.c_double))
+        k1, p1 = ptr(top_flux_dn_sw)
+        k2, p2 = ptr(top_flux_dn_direct_sw)
+        k3, p3 = ptr(top_flux_dn_lw)
+        _check(self._lib.ss_plan_scale_and_sum(self._h, p1, p2, p3))
+
+    def download_sums(self, sw_flux=None, lw_flux=None):
+        cs = sw_flux.to_c() if sw_flux is not None else None
+        cl = lw_flux.to_c() if lw_flux is not None else None
+        _check(self._lib.ss_plan_download_sums(self._h, C.byref(cs) if cs is not None else None,
+                                               C.byref(cl) if cl is not None else None))
 
     def set_pipes(self, npipes):
         """Concurrent streams used by solve(): 1 = serial kernels, 2 = overlapped chunks."""

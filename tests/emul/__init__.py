@@ -40,3 +40,32 @@ def run_emul(config, cp, sw, lw, want_profiles=True, do_simple_spectrum=False,
     if rc != 0:
         raise RuntimeError("emulated HIP path returned %d" % rc)
     return out, nfail.value
+
+
+def run_scale_sum_emul(config, cp, sw, lw, top_sw, top_sw_dir, top_lw, want_profiles=True):
+    """solve + scale_and_sum through the emulated plan; returns (outputs, sw_flux, lw_flux)."""
+    import numpy as np
+    from oracle import checker
+    from spartacus_surface_amd import types
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB)
+    out = checker.alloc_outputs(config, cp, want_profiles)
+    keep, args = checker._common_args(config, cp, sw, lw, out, 1, cp.ncol)
+    sums = []
+    for nspec, direct in ((config.nsw, True), (config.nlw, False)):
+        f = types.CanopyFlux()
+        f.allocate(config, cp.ncol, cp.ntotlay, nspec, use_direct=direct, do_save_flux_profile=want_profiles)
+        sums.append(f)
+    cs = [f.to_c() for f in sums]
+    dp = C.POINTER(C.c_double)
+    arrs = [np.ascontiguousarray(a, dtype=np.float64) if a is not None else None
+            for a in (top_sw, top_sw_dir, top_lw)]
+    ptrs = [a.ctypes.data_as(dp) if a is not None else None for a in arrs]
+    _lib.spartacus_scale_sum_emul.restype = C.c_int
+    rc = _lib.spartacus_scale_sum_emul(*args, C.c_int32(int(want_profiles)), *ptrs,
+                                       C.byref(cs[0]), C.byref(cs[1]))
+    if rc != 0:
+        raise RuntimeError("emulated scale_and_sum returned %d" % rc)
+    return out, sums[0], sums[1]

@@ -54,6 +54,13 @@ struct EmulBackend {
       else ss::column_unit_sw<U, R, NS>(L, cu);
     }
   }
+  static void launch_scale_sum(const ss::ScaleSumLaunch& S, Timers&) {
+    for (int kind = 0; kind < 4; ++kind) {
+      const long n = kind == 0 ? (long)S.nspec * S.ncols : kind == 1 ? (long)S.nspec * S.nlays
+                   : kind == 2 ? S.ncols : S.nlays;
+      for (long i = 0; i < n; ++i) ss::scale_sum_unit(S, kind, i);
+    }
+  }
   static void fork(int) {}
   static void join(int) {}
   static void launch_solver(const ss::ClassKey& key, bool lw, const ss::Launch& L, Timers&, int) {
@@ -64,6 +71,27 @@ struct EmulBackend {
 };
 
 }  // namespace
+
+// solve + canopy_flux%scale/%sum: returns the scaled objects and the two sums
+extern "C" int spartacus_scale_sum_emul(const ss_config* config, const ss_canopy* canopy,
+                                        const ss_sw_spectral* sw, const ss_lw_spectral* lw,
+                                        ss_bc_out* bc_out, int32_t istartcol, int32_t iendcol,
+                                        ss_flux* sw_norm_dir, ss_flux* sw_norm_diff,
+                                        ss_flux* lw_internal, ss_flux* lw_norm, int32_t want_profiles,
+                                        const double* top_sw, const double* top_sw_dir, const double* top_lw,
+                                        ss_flux* sw_flux, ss_flux* lw_flux) {
+  ss::Plan<EmulBackend> plan;
+  int rc = plan.create(config, canopy, sw, lw, istartcol, iendcol, want_profiles);
+  if (rc) return rc;
+  plan.upload_outputs(bc_out, sw_norm_dir, sw_norm_diff, lw_internal, lw_norm);
+  rc = plan.solve();
+  if (rc) return rc;
+  rc = plan.scale_and_sum(top_sw, top_sw_dir, top_lw);
+  if (rc) return rc;
+  rc = plan.download(bc_out, sw_norm_dir, sw_norm_diff, lw_internal, lw_norm);
+  if (rc) return rc;
+  return plan.download_sums(sw_flux, lw_flux);
+}
 
 extern "C" int spartacus_radsurf_emul(const ss_config* config, const ss_canopy* canopy,
                                       const ss_sw_spectral* sw, const ss_lw_spectral* lw,

@@ -6,7 +6,7 @@ tag=${1:-main}
 export TMPDIR=/tmp
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python bench.py --steps 5 --warmup 2 > $out/bench_under_rocprof.json 2> $out/trace.log || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python bench.py --steps 5 --warmup 2 --no-extras > $out/bench_under_rocprof.json 2> $out/trace.log || exit 1
 timeout -k 10 300 python bench.py --steps 5 --warmup 2 > $out/bench.json 2> $out/bench.log || exit 1
 mkdir -p gpurun_out/pmc_$tag
 P="python bench.py --steps 1 --warmup 0 --columns 200000 --no-cpu-baseline"
