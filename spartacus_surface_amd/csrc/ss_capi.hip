@@ -74,10 +74,10 @@ __global__ void __launch_bounds__(256) k_spectrum_lay(const ss::SpectrumLaunch S
 }
 
 __global__ void __launch_bounds__(256) k_scale_sum(const ss::ScaleSumLaunch S) {
-  // blockIdx.y = member kind (ss::scale_sum_unit)
+  // blockIdx.y = member kind (ss::scale_sum_unit); one aligned element pair per thread
   const int kind = blockIdx.y;
-  const long n = kind == 0 ? (long)S.nspec * S.ncols : kind == 1 ? (long)S.nspec * S.nlays
-               : kind == 2 ? S.ncols : S.nlays;
+  long first;
+  const long n = ss::scale_sum_pairs(S, kind, &first);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     ss::scale_sum_unit(S, kind, i);
 }
@@ -180,8 +180,8 @@ struct HipBackend {
     t.spans.push_back({FAM_MISC, a, b});
   }
   static void launch_scale_sum(const ss::ScaleSumLaunch& S, Timers& t) {
-    const long nmax = (long)S.nspec * std::max(S.ncols, S.nlays);
-    if (nmax <= 0) return;
+    const long nmax = ((long)S.nspec * std::max(S.ncols, S.nlays)) / 2 + 1;
+    if (S.ncols <= 0) return;
     const unsigned gx = (unsigned)std::min<long>((nmax + 255) / 256, 1L << 20);
     hipEvent_t a = t.next(), b = t.next();
     hipEventRecord(a, stream());

@@ -62,7 +62,10 @@ struct LwRec {
 };
 
 // 16-byte element pair of the scratch
+#ifndef SS_RECPAIR_DEFINED
+#define SS_RECPAIR_DEFINED
 struct alignas(16) RecPair { double x, y; };
+#endif
 
 // Lanes per scratch tile (= wavefront size) and the element stride inside a tile
 constexpr long kRecStride = 64;

@@ -10,6 +10,12 @@
 
 namespace ss {
 
+#ifndef SS_RECPAIR_DEFINED
+#define SS_RECPAIR_DEFINED
+// 16-byte element pair
+struct alignas(16) RecPair { double x, y; };
+#endif
+
 struct MiscLaunch {
   Inputs in;
   const int32_t* cols;
@@ -121,44 +127,82 @@ struct ScaleSumLaunch {
   long lay0, nlays;        // packed layer range
 };
 
-// kind 0: one (band, column) element of every (nspec, ncol) member;
-// kind 1: one (band, layer) element of every (nspec, ntotlay) member;
-// kind 2 / 3: one column / layer of the unscaled (ncol) / (ntotlay) members
+// kind 0: (band, column) elements of every (nspec, ncol) member;
+// kind 1: (band, layer) elements of every (nspec, ntotlay) member;
+// kind 2 / 3: columns / layers of the unscaled (ncol) / (ntotlay) members.
+// Unit i handles the aligned element pair (2i, 2i+1) of the kind's index space
+// (16-byte accesses; arrays are 16-byte aligned), restricted to the plan's range.
+SS_HD long scale_sum_pairs(const ScaleSumLaunch& S, int kind, long* first) {
+  const long lo = kind == 0 ? (long)S.nspec * S.col0 : kind == 1 ? (long)S.nspec * S.lay0
+                : kind == 2 ? S.col0 : S.lay0;
+  const long n = kind == 0 ? (long)S.nspec * S.ncols : kind == 1 ? (long)S.nspec * S.nlays
+               : kind == 2 ? S.ncols : S.nlays;
+  *first = lo & ~1L;
+  return n > 0 ? ((lo + n + 1) / 2 - lo / 2) : 0;
+}
+
 SS_HD void scale_sum_unit(const ScaleSumLaunch& S, int kind, long i) {
 #if defined(__clang__)
 #pragma clang fp contract(off)   // the reference rounds the product before the sum
 #endif
-  long idx, fidx = 0;
-  if (kind == 0) {
-    idx = (long)S.nspec * S.col0 + i;
-    fidx = idx;
-  } else if (kind == 1) {
-    idx = (long)S.nspec * S.lay0 + i;
-    const long lay = idx / S.nspec, spec = idx - lay * S.nspec;
-    fidx = spec + (long)S.nspec * S.indcol[lay];
-  } else if (kind == 2) {
-    idx = S.col0 + i;
-  } else {
-    idx = S.lay0 + i;
-  }
+  const long lo = kind == 0 ? (long)S.nspec * S.col0 : kind == 1 ? (long)S.nspec * S.lay0
+                : kind == 2 ? S.col0 : S.lay0;
+  const long hi = lo + (kind == 0 ? (long)S.nspec * S.ncols : kind == 1 ? (long)S.nspec * S.nlays
+                        : kind == 2 ? S.ncols : S.nlays);
+  const long e0 = (lo & ~1L) + 2 * i;
+  const bool in0 = e0 >= lo && e0 < hi, in1 = e0 + 1 >= lo && e0 + 1 < hi;
+  if (!in0 && !in1) return;
   const bool scaled = (kind <= 1);
-  const double fa = (scaled && S.fa) ? S.fa[fidx] : 1.0;
-  const double fb = (scaled && S.fb) ? S.fb[fidx] : 1.0;
+  double fa0 = 1.0, fa1 = 1.0, fb0 = 1.0, fb1 = 1.0;
+  if (scaled) {
+    long f0 = e0, f1 = e0 + 1;
+    if (kind == 1) {
+      const long l0 = e0 / S.nspec, l1 = (e0 + 1) / S.nspec;
+      f0 = (e0 - l0 * S.nspec) + (long)S.nspec * S.indcol[in0 ? l0 : l1];
+      f1 = (e0 + 1 - l1 * S.nspec) + (long)S.nspec * S.indcol[in1 ? l1 : l0];
+    }
+    if (S.fa) { if (in0) fa0 = S.fa[f0]; if (in1) fa1 = S.fa[f1]; }
+    if (S.fb) { if (in0) fb0 = S.fb[f0]; if (in1) fb1 = S.fb[f1]; }
+  }
+  const bool both = in0 && in1;
   for (int F = 0; F < F_NFIELDS; ++F) {
     if (flux_field_shape(F) != kind) continue;
     double* pa = S.a.f[F];
     double* pb = S.b.f[F];
     double* ps = S.sum.f[F];
-    double va = 0.0, vb = 0.0;
+    RecPair va = {0.0, 0.0}, vb = {0.0, 0.0};
     if (pa) {
-      va = pa[idx];
-      if (scaled && S.fa) { va = fa * va; pa[idx] = va; }
+      if (both) va = *reinterpret_cast<const RecPair*>(pa + e0);
+      else if (in0) va.x = pa[e0];
+      else va.y = pa[e0 + 1];
+      if (scaled && S.fa) {
+        va.x = fa0 * va.x;
+        va.y = fa1 * va.y;
+        if (both) *reinterpret_cast<RecPair*>(pa + e0) = va;
+        else if (in0) pa[e0] = va.x;
+        else pa[e0 + 1] = va.y;
+      }
     }
     if (pb) {
-      vb = pb[idx];
-      if (scaled && S.fb) { vb = fb * vb; pb[idx] = vb; }
+      if (both) vb = *reinterpret_cast<const RecPair*>(pb + e0);
+      else if (in0) vb.x = pb[e0];
+      else vb.y = pb[e0 + 1];
+      if (scaled && S.fb) {
+        vb.x = fb0 * vb.x;
+        vb.y = fb1 * vb.y;
+        if (both) *reinterpret_cast<RecPair*>(pb + e0) = vb;
+        else if (in0) pb[e0] = vb.x;
+        else pb[e0 + 1] = vb.y;
+      }
     }
-    if (ps) ps[idx] = va + vb;
+    if (ps) {
+      RecPair vs;
+      vs.x = va.x + vb.x;
+      vs.y = va.y + vb.y;
+      if (both) *reinterpret_cast<RecPair*>(ps + e0) = vs;
+      else if (in0) ps[e0] = vs.x;
+      else ps[e0 + 1] = vs.y;
+    }
   }
 }
 

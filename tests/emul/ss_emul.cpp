@@ -56,8 +56,8 @@ struct EmulBackend {
   }
   static void launch_scale_sum(const ss::ScaleSumLaunch& S, Timers&) {
     for (int kind = 0; kind < 4; ++kind) {
-      const long n = kind == 0 ? (long)S.nspec * S.ncols : kind == 1 ? (long)S.nspec * S.nlays
-                   : kind == 2 ? S.ncols : S.nlays;
+      long first;
+      const long n = ss::scale_sum_pairs(S, kind, &first);
       for (long i = 0; i < n; ++i) ss::scale_sum_unit(S, kind, i);
     }
   }
