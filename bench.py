@@ -192,9 +192,19 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    # SPARTACUS_BENCH_REHEARSAL=1: N ranks on fewer GPUs (ranks share devices, gloo
+    # instead of RCCL, gathers staged through the host) - only to rehearse the N > 1
+    # code path on a one-GPU box; its numbers mean nothing.
+    rehearsal = os.environ.get("SPARTACUS_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    cdev = "cpu" if rehearsal else "cuda"
 
     from spartacus_surface_amd import radsurf, workloads
     radsurf.load_library()
@@ -208,12 +218,13 @@ def main():
     if world > 1:
         names = ("bc_out.sw_albedo", "bc_out.sw_albedo_dir", "bc_out.lw_emissivity", "bc_out.lw_emission")
         views = [torch.as_tensor(_DevArray(*plan.device_ptr(n)), device="cuda") for n in names]
-        outs = [torch.empty(world * v.numel(), dtype=torch.float64, device="cuda") for v in views]
+        outs = [torch.empty(world * v.numel(), dtype=torch.float64, device=cdev) for v in views]
 
         def gather():
-            plan.synchronize()
+            plan.synchronize()                      # results of the library's streams are complete
             for v, o in zip(views, outs):
-                dist.all_gather_into_tensor(o, v)
+                dist.all_gather_into_tensor(o, v.cpu() if rehearsal else v)
+            torch.cuda.synchronize()                # ... and gathered before the next solve overwrites them
 
     def step():
         plan.solve()
@@ -241,7 +252,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     nfail = plan.eigen_failures()
@@ -312,7 +323,7 @@ def main():
                 "traffic": measured_traffic(sd, s_cols, args.workload)[0],
                 "fp64_tflops": fpc * args.columns / (s_tot * 1e-3) / 1e12,
                 "fp64_frac": fpc * args.columns / (s_tot * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
-        if not args.no_extras and case.get("top_flux_dn_sw") is not None:
+        if world == 1 and not args.no_extras and case.get("top_flux_dn_sw") is not None:
             line["scale_sum"] = scale_sum_rate(plan, case, args.columns)
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
             line["cpu_baseline"] = cpu_baseline(args.workload, min(args.cpu_sample, args.columns))
