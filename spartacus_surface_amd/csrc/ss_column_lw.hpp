@@ -57,7 +57,7 @@ SS_HD void lw_adding_step(const double* Aab, const double* Sab, const double* R,
 }
 
 // ---- section 4: adding method with sources, upward (k_up) ----
-template <bool URBAN, int NREG, int NS, bool FUSED = false>
+template <bool URBAN, int NREG, int NS>
 SS_HD void column_up_lw(const Launch& L, int cu) {
   constexpr int N = NREG * NS;
   constexpr int DB = URBAN ? NREG + 1 : NREG;
@@ -94,7 +94,6 @@ SS_HD void column_up_lw(const Launch& L, int cu) {
   }
 
   for (int jlay = 0; jlay < nlay; ++jlay) {
-    if (FUSED) layer_unit_lw<URBAN, NREG, NS>(L, cu, jlay);
     const double* lrec = L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu);
     double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
     const int lay = l0 + jlay;

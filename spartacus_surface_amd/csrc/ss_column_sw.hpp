@@ -70,10 +70,7 @@ struct SwColCtx {
 };
 
 // ---- section 4: adding method upward (k_up) ----
-// FUSED: the lane first computes the layer matrices of each layer itself
-// (layer_unit_sw) and reads them back from its own scratch record, which is
-// then still in cache.
-template <bool URBAN, int NREG, int NS, bool FUSED = false>
+template <bool URBAN, int NREG, int NS>
 SS_HD void column_up_sw(const Launch& L, int cu) {
   constexpr int N = NREG * NS, D = NREG;
   constexpr int DB = URBAN ? NREG + 1 : NREG;
@@ -105,7 +102,6 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
   }
 
   for (int jlay = 0; jlay < nlay; ++jlay) {
-    if (FUSED) layer_unit_sw<URBAN, NREG, NS>(L, cu, jlay);
     const double* lrec = L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu);
     double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
     const long sidx = (long)jb + (long)nspec * (l0 + jlay);

@@ -13,6 +13,14 @@
 namespace ss {
 namespace {
 
+// Matrix orders above SS_UNROLL_MAX run on runtime loops with their matrices in
+// scratch memory: registers do not limit them, latency does, so they are built
+// for several waves per SIMD (SS_BIG_WAVES) instead of one.
+#ifndef SS_BIG_WAVES
+#define SS_BIG_WAVES 4
+#endif
+#define SS_WAVES(R, NS, small) (((R) * (NS) > SS_UNROLL_MAX) ? SS_BIG_WAVES : (small))
+
 #ifndef SS_MIN_WAVES_LAYER
 #define SS_MIN_WAVES_LAYER 1
 #endif
@@ -24,7 +32,7 @@ namespace {
 #endif
 
 template <bool U, int R, int NS, bool LW>
-__global__ void __launch_bounds__(kBlock, SS_MIN_WAVES_LAYER) k_layer(const Launch L) {
+__global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_LAYER)) k_layer(const Launch L) {
   const int cu = blockIdx.x * kBlock + threadIdx.x;
   if (cu >= L.ncu) return;
   if (LW) layer_unit_lw<U, R, NS>(L, cu, (int)blockIdx.y);
@@ -33,25 +41,16 @@ __global__ void __launch_bounds__(kBlock, SS_MIN_WAVES_LAYER) k_layer(const Laun
 
 // upward sweep (adding method)
 template <bool U, int R, int NS, bool LW>
-__global__ void __launch_bounds__(kBlock, SS_MIN_WAVES_COLUMN) k_column(const Launch L) {
+__global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_COLUMN)) k_column(const Launch L) {
   const int cu = blockIdx.x * kBlock + threadIdx.x;
   if (cu >= L.ncu) return;
   if (LW) column_up_lw<U, R, NS>(L, cu);
   else column_up_sw<U, R, NS>(L, cu);
 }
 
-// layer matrices + upward sweep of a whole column on one lane
-template <bool U, int R, int NS, bool LW>
-__global__ void __launch_bounds__(kBlock, 1) k_layer_up(const Launch L) {
-  const int cu = blockIdx.x * kBlock + threadIdx.x;
-  if (cu >= L.ncu) return;
-  if (LW) column_up_lw<U, R, NS, true>(L, cu);
-  else column_up_sw<U, R, NS, true>(L, cu);
-}
-
 // downward flux sweep: vectors only, several waves per SIMD
 template <bool U, int R, int NS, bool LW>
-__global__ void __launch_bounds__(kBlock, SS_MIN_WAVES_DOWN) k_down(const Launch L) {
+__global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_DOWN)) k_down(const Launch L) {
   const int unit = blockIdx.x * kBlock + threadIdx.x;   // (column unit, pass), pass fastest
   const int cu = unit >> 1;
   if (cu >= L.ncu) return;
@@ -74,17 +73,11 @@ void launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev) {
   }
   const unsigned gx = (unsigned)((L.ncu + kBlock - 1) / kBlock);
   if (ev) hipEventRecord(ev[0], stream);
-#ifdef SS_FUSED_UP
-  hipLaunchKernelGGL((k_layer_up<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx), dim3(kBlock), 0,
-                     stream, L);
-  if (ev) hipEventRecord(ev[1], stream);
-#else
   hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx, (unsigned)L.maxlay),
                      dim3(kBlock), 0, stream, L);
   if (ev) hipEventRecord(ev[1], stream);
   hipLaunchKernelGGL((k_column<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx), dim3(kBlock), 0,
                      stream, L);
-#endif
   if (ev) hipEventRecord(ev[2], stream);
   {
     const unsigned gd = (unsigned)((2L * L.ncu + kBlock - 1) / kBlock);

@@ -1,8 +1,9 @@
 #!/bin/bash
-# usage: run_variants.sh name1 name2 ... ; runs bench for each variant lib
+# usage: run_variants.sh "bench args" name1 name2 ... ; runs bench for each variant lib
+args=$1; shift
 mkdir -p gpurun_out/exp
 for v in "$@"; do
-  SPARTACUS_HIP_LIB=$PWD/spartacus_surface_amd/lib/variants/libss_$v.so timeout -k 10 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/exp/$v.json 2> gpurun_out/exp/$v.err || echo "$v failed"
+  SPARTACUS_HIP_LIB=$PWD/spartacus_surface_amd/lib/variants/libss_$v.so timeout -k 10 300 python bench.py --steps 2 --warmup 1 --no-extras $args > gpurun_out/exp/$v.json 2> gpurun_out/exp/$v.err || echo "$v failed"
   python - "$v" <<'PY'
 import json, sys
 v = sys.argv[1]
