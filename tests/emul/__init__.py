@@ -42,7 +42,8 @@ def run_emul(config, cp, sw, lw, want_profiles=True, do_simple_spectrum=False,
     return out, nfail.value
 
 
-def run_scale_sum_emul(config, cp, sw, lw, top_sw, top_sw_dir, top_lw, want_profiles=True):
+def run_scale_sum_emul(config, cp, sw, lw, top_sw, top_sw_dir, top_lw, want_profiles=True,
+                       istartcol=1, iendcol=None):
     """solve + scale_and_sum through the emulated plan; returns (outputs, sw_flux, lw_flux)."""
     import numpy as np
     from oracle import checker
@@ -52,7 +53,8 @@ def run_scale_sum_emul(config, cp, sw, lw, top_sw, top_sw_dir, top_lw, want_prof
         build()
         _lib = C.CDLL(LIB)
     out = checker.alloc_outputs(config, cp, want_profiles)
-    keep, args = checker._common_args(config, cp, sw, lw, out, 1, cp.ncol)
+    keep, args = checker._common_args(config, cp, sw, lw, out, istartcol,
+                                      cp.ncol if iendcol is None else iendcol)
     sums = []
     for nspec, direct in ((config.nsw, True), (config.nlw, False)):
         f = types.CanopyFlux()

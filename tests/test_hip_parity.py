@@ -234,3 +234,33 @@ def test_full_size_properties_c3():
              + lay("veg_air_abs") + lay("roof_net") + lay("wall_net")
              - got_big["sw_norm_dir.top_net"].sum(axis=1))
     assert np.max(np.abs(resid)) < 5.0e-3
+
+
+def test_pipes_and_chunking_do_not_change_results(monkeypatch):
+    """The schedule (1 / 2 / 4 concurrent streams, one big chunk or many small
+    ones) is invisible in the results: bit-identical outputs."""
+    from oracle import checker
+    from spartacus_surface_amd import workloads
+    radsurf = _hip()
+    case = workloads.c4_mixed(ncol=3000, seed=4242, nsw=3, nlw=2)
+    cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
+
+    def run(pipes, scratch_mb):
+        if scratch_mb is None:
+            monkeypatch.delenv("SPARTACUS_SCRATCH_MB", raising=False)
+        else:
+            monkeypatch.setenv("SPARTACUS_SCRATCH_MB", str(scratch_mb))
+        plan = radsurf.Plan(cfg, cp, sw, lw, want_profiles=True)
+        plan.set_pipes(pipes)
+        plan.solve()
+        out = checker.alloc_outputs(cfg, cp, True)
+        plan.download(out["bc_out"], out["sw_norm_dir"], out["sw_norm_diff"], out["lw_internal"],
+                      out["lw_norm"])
+        plan.close()
+        return fixture_io.flatten_outputs(out)
+
+    base = run(1, None)
+    for pipes, mb in ((2, None), (4, 16), (1, 16), (2, 4)):
+        other = run(pipes, mb)
+        for k, v in base.items():
+            assert np.array_equal(v, other[k]), (pipes, mb, k)

@@ -105,6 +105,31 @@ def test_emulated_device_scale_sum(path):
     _assert_bitwise(got, want, name)
 
 
+def test_emulated_scale_sum_on_a_column_range():
+    """Only the plan's column range [istartcol, iendcol] is scaled and summed
+    (odd offsets exercise the unaligned ends of the 16-byte pair kernel)."""
+    from tests import emul
+    path = [p for p in FILES if "test_surfaces" in p][0]
+    name, case, _, gold = _load(path)
+    t = (gold["top_flux_dn_sw"], gold["top_flux_dn_direct_sw"], gold["top_flux_dn_lw"])
+    cp = case["canopy"]
+    i0, i1 = 2, 3
+    full_out, full_sw, full_lw = emul.run_scale_sum_emul(case["config"], cp, case["sw"], case["lw"], *t)
+    out, sw_flux, lw_flux = emul.run_scale_sum_emul(case["config"], cp, case["sw"], case["lw"], *t,
+                                                    istartcol=i0, iendcol=i1)
+    l0 = int(cp.istartlay[i0 - 1] - 1)
+    l1 = int(cp.istartlay[i1 - 1] - 1 + cp.nlay[i1 - 1])
+    for got, ref in ((sw_flux, full_sw), (lw_flux, full_lw)):
+        for k, v in got.fields().items():
+            r = ref.fields()[k]
+            if v.shape[0] == cp.ncol:
+                assert np.array_equal(v[i0 - 1:i1], r[i0 - 1:i1]), k
+                assert not np.any(v[:i0 - 1]) and not np.any(v[i1:]), k      # untouched outside
+            else:
+                assert np.array_equal(v[l0:l1], r[l0:l1]), k
+                assert not np.any(v[:l0]) and not np.any(v[l1:]), k
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", FILES, ids=lambda p: os.path.basename(p)[:-4])
 def test_device_scale_sum(path):
