@@ -29,7 +29,15 @@ SS_HD int eigen_decomposition_real_dynamic(const double* amat, double* eigenvalu
 // (scratch) above that.
 template <int N>
 SS_HD int eigen_decomposition_real(const double* amat, double* eigenvalue, double* eigenvector) {
-#ifndef SS_EIGEN_DYNAMIC_ONLY
+#if defined(SS_TIMING_NO_EIGEN)   // timing experiment only: wrong results
+  if constexpr (N >= 3) {
+    for (int i = 0; i < N; ++i) {
+      eigenvalue[i] = amat[i + i * N];
+      for (int j = 0; j < N; ++j) eigenvector[i + j * N] = (i == j) ? 1.0 : 0.01 * amat[i + j * N];
+    }
+    return 0;
+  } else
+#elif !defined(SS_EIGEN_DYNAMIC_ONLY)
   if constexpr (N >= 3 && N <= SS_UNROLL_MAX) {
     return eigen_decomposition_real_static<N>(amat, eigenvalue, eigenvector);
   } else
