@@ -1,0 +1,21 @@
+"""The register-resident eigen routine (ss_eigen_static.hpp, orders 3..6) must be
+bit-identical to the run-time-indexed one (ss_eigen.hpp): same arithmetic,
+different addressing.  tests/emul/eigen_check.cpp runs both on 16000 random
+Gamma-like matrices (block-diagonal, triangular, diagonal, degenerate and
+isolated-eigenvalue cases included) compiled for the host.  The dynamic routine
+in turn is checked against the reference's eigen_decomposition_real through the
+oracle (tests/test_oracle_vs_reference.py)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_static_eigen_is_bit_identical_to_dynamic(tmp_path):
+    exe = str(tmp_path / "eigen_check")
+    # -ffp-contract=off: both forms must round every operation the same way
+    subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-Wno-unknown-pragmas", "-o", exe,
+                    os.path.join(HERE, "emul", "eigen_check.cpp")], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert r.stdout.count("0 mismatches") == 4, r.stdout
