@@ -147,6 +147,22 @@ struct Launch {
   unsigned long long* eigen_fail;   // count of non-converged eigenproblems
 };
 
+// In-kernel section stamps (profiling builds only, -DSS_STAMPS): lane 0 of every
+// wave adds the s_memtime ticks spent since the previous stamp to counter k of
+// the buffer behind Launch::eigen_fail (slot 0 stays the eigen-failure count;
+// print with SPARTACUS_PRINT_STAMPS=1).  The stamps perturb the schedule
+// (k_layer +45 %), read them as proportions.
+#if defined(SS_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define SS_STAMP_DECL(ptr) unsigned long long* ss_stamp_buf_ = (ptr); \
+  unsigned long long ss_stamp_t_ = __builtin_amdgcn_s_memtime()
+#define SS_STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    if (ss_stamp_buf_ && (threadIdx.x & 63) == 0) atomicAdd(ss_stamp_buf_ + 1 + (k), t_ - ss_stamp_t_); \
+    ss_stamp_t_ = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SS_STAMP_DECL(ptr) do {} while (0)
+#define SS_STAMP(k) do {} while (0)
+#endif
+
 // element (i,j) of a column-major matrix with R rows
 #define SS_E(a, i, j, R) ((a)[(i) + (j) * (R)])
 

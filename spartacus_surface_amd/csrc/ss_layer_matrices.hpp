@@ -102,6 +102,7 @@ SS_HD void rec_store(double* rec, long stride, int off, const double* src) {
 struct RecWriter {
   double* rec;
   long stride;
+  unsigned long long* stamps;   // profiling builds (SS_STAMPS): section counters, else unused
   // elements e (even) and e+1
   SS_HD void put2(int e, double v0, double v1) const {
     RecPair v;
@@ -164,7 +165,9 @@ struct Diffuse {
 
 template <int N, class PutR, class PutT>
 SS_HD int diffuse_part(const double* g1, const double* g2, double dz, Diffuse<N>& w,
-                       const PutR& putR, const PutT& putT) {
+                       const PutR& putR, const PutT& putT, unsigned long long* stamps = nullptr,
+                       int stamp0 = 0) {
+  SS_STAMP_DECL(stamps);
   double GD[N * N], P[N * N], X[N * N], ev[N];
   int ierr;
   {
@@ -176,7 +179,9 @@ SS_HD int diffuse_part(const double* g1, const double* g2, double dz, Diffuse<N>
     }
     mat_mul<N, N, N>(GD, GS, P);
   }
+  SS_STAMP(stamp0);
   ierr = eigen_decomposition_real<N>(P, ev, X);
+  SS_STAMP(stamp0 + 1);
   SS_UNROLL_N(N)
   for (int j = 0; j < N; ++j) {
     w.lam[j] = sqrt(ss_max(0.0, ev[j]));
@@ -225,6 +230,7 @@ SS_HD int diffuse_part(const double* g1, const double* g2, double dz, Diffuse<N>
     mat_mul_rs<N, N, N, true>(w.G1, w.e, w.Clo, t1);
     putT(t1);
   }
+  SS_STAMP(stamp0 + 2);
   return ierr;
 }
 
@@ -234,6 +240,7 @@ template <int NF, int DF, int N, int D, int I0, int R0>
 SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
                            const double* g3, double dz, const RecWriter& w) {
   using Rec = SwRec<NF, DF>;
+  SS_STAMP_DECL(w.stamps);
   int ierr = 0;
   double mu[D], G0[D * D], G0inv[D * D], emu[D];
   double g3v[N * D], g4v[N * D];   // particular solutions, one column per direct eigenvalue
@@ -276,6 +283,7 @@ SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
     put_embedded<NF, DF, N, D, I0, R0>(w, Rec::IDD, v);
   }
 
+  SS_STAMP(1);
   // Section 3 (:223-229): E = G0 diag(exp(mu dz)) G0^-1
   ierr += eigen_decomposition_real<D>(g0, mu, G0);
   {
@@ -326,12 +334,14 @@ SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
     }
   }
 
+  SS_STAMP(2);
   // Sections 1-2: diffuse R, T
   Diffuse<N> df;
   ierr += diffuse_part<N>(
       g1, g2, dz, df,
       [&](const double* R) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::R, R); },
-      [&](const double* T) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::T, T); });
+      [&](const double* T) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::T, T); }, w.stamps, 3);
+  SS_STAMP(20);   // (re-arm)
 
   // direct_diffuse_part (:303-386) by block elimination (see header comment)
   {
@@ -381,6 +391,7 @@ SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
     }
     put_embedded<NF, DF, N, D, I0, R0>(w, Rec::SDN, t);
   }
+  SS_STAMP(6);
 
   return ierr;
 }
@@ -390,6 +401,7 @@ template <int NF, int N, int I0>
 SS_HD int calc_matrices_lw(const double* g1, const double* g2, const double* b, double dz,
                            const RecWriter& w) {
   using Rec = LwRec<NF>;
+  SS_STAMP_DECL(w.stamps);
   // Section 3 (:178-195): inv_gamma_b (first, while only the Gamma matrices are live)
   double igb[N];
   {
@@ -407,11 +419,13 @@ SS_HD int calc_matrices_lw(const double* g1, const double* g2, const double* b, 
     lu_factor<N>(M);
     lu_solve<N>(M, igb);
   }
+  SS_STAMP(12);
   Diffuse<N> df;
   int ierr = diffuse_part<N>(
       g1, g2, dz, df,
       [&](const double* R) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::R, R); },
-      [&](const double* T) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::T, T); });
+      [&](const double* T) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::T, T); }, w.stamps, 13);
+  SS_STAMP(20);   // (re-arm)
 
   // Section 4 (:198-209): cb' and the source
   double cb[N], v[N];
@@ -453,6 +467,7 @@ SS_HD int calc_matrices_lw(const double* g1, const double* g2, const double* b, 
     mat_vec<N, N>(GZ, cb, v);
     put_embedded_vec<NF, N, I0>(w, Rec::ISRC, [&](int i) { return 2.0 * (v[i] + igb[i] * dz); });
   }
+  SS_STAMP(16);
   return ierr;
 }
 

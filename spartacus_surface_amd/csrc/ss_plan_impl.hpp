@@ -23,6 +23,7 @@
 #pragma once
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -134,6 +135,8 @@ class Plan {
   static constexpr int kDefaultPipes = 2;
   int pipes_wanted = kDefaultPipes;
   size_t lay_bytes = 0, col_bytes = 0;
+  // slot 0: eigen failures of the last solve; the rest: section stamps of profiling builds
+  static constexpr int kCounters = 32;
   unsigned long long* d_eigen_fail = nullptr;
 
   typename Backend::Timers timers;
@@ -258,8 +261,8 @@ class Plan {
     ensure("bc_out.lw_emission", std::max<size_t>(1, (size_t)nlw * ncol));
     if (cfg.do_sw) { alloc_flux("sw_norm_dir", nsw, true); alloc_flux("sw_norm_diff", nsw, true); }
     if (cfg.do_lw) { alloc_flux("lw_internal", nlw, false); alloc_flux("lw_norm", nlw, false); }
-    d_eigen_fail = static_cast<unsigned long long*>(Backend::alloc(sizeof(unsigned long long)));
-    Backend::memset(d_eigen_fail, 0, sizeof(unsigned long long));
+    d_eigen_fail = static_cast<unsigned long long*>(Backend::alloc(kCounters * sizeof(unsigned long long)));
+    Backend::memset(d_eigen_fail, 0, kCounters * sizeof(unsigned long long));
     return upload(can, sw, lw);
   }
 
@@ -585,7 +588,7 @@ class Plan {
   // ---- one pass of the hot path ----
   int solve() {
     timers.begin_solve();
-    Backend::memset_async(d_eigen_fail, 0, sizeof(unsigned long long));
+    Backend::memset_async(d_eigen_fail, 0, kCounters * sizeof(unsigned long long));
     if (!flat_cols.empty()) {
       if (cfg.do_sw && (!darr("sw.ground_albedo"))) { error = "sw.ground_albedo missing"; return SS_ERR_BAD_ARGUMENT; }
       if (cfg.do_lw && (!darr("lw.ground_emissivity") || !darr("lw.ground_emission"))) { error = "lw ground arrays missing"; return SS_ERR_BAD_ARGUMENT; }
@@ -780,9 +783,14 @@ class Plan {
 
   long long eigen_failures() {
     Backend::sync();
-    unsigned long long v = 0;
-    Backend::d2h(&v, d_eigen_fail, sizeof(v));
-    return (long long)v;
+    unsigned long long v[kCounters] = {0};
+    Backend::d2h(v, d_eigen_fail, sizeof(v));
+    if (std::getenv("SPARTACUS_PRINT_STAMPS")) {
+      std::fprintf(stderr, "stamps:");
+      for (int k = 1; k < kCounters; ++k) std::fprintf(stderr, " %llu", v[k]);
+      std::fprintf(stderr, "\n");
+    }
+    return (long long)v[0];
   }
 };
 

@@ -89,6 +89,7 @@ SS_HD void lw_layer_props(const Launch& L, int lay, long sidx, LwLayerProps<URBA
 
 template <bool URBAN, int NREG, int NS>
 SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay) {
+  SS_STAMP_DECL((unsigned long long*)L.eigen_fail);
   constexpr int N = NREG * NS;
   using Rec = LwRec<N>;
   const Inputs& in = L.in;
@@ -171,7 +172,8 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay) {
     }
   }
 
-  RecWriter w{L.lay + rec_base(jlay, L.maxlay, Rec::NELEM, cu), kRecStride};
+  RecWriter w{L.lay + rec_base(jlay, L.maxlay, Rec::NELEM, cu), kRecStride, (unsigned long long*)L.eigen_fail};
+  SS_STAMP(10);
   int ierr;
   if (NREG == 1 || p.g.veg_fraction <= L.cfg.min_vegetation_fraction) {
     double s1[NS * NS], s2[NS * NS];

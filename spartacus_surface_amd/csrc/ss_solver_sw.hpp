@@ -52,6 +52,7 @@ SS_HD void region_optics(double air_ext, double air_ssa, double veg_ext, double 
 
 template <bool URBAN, int NREG, int NS>
 SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay) {
+  SS_STAMP_DECL((unsigned long long*)L.eigen_fail);
   constexpr int N = NREG * NS, D = NREG;
   using Rec = SwRec<N, D>;
   const Inputs& in = L.in;
@@ -164,7 +165,8 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay) {
   }
 
   // ---- layer matrices, 3-way branch (forest :408-455, urban :520-583) ----
-  RecWriter w{L.lay + rec_base(jlay, L.maxlay, Rec::NELEM, cu), kRecStride};
+  RecWriter w{L.lay + rec_base(jlay, L.maxlay, Rec::NELEM, cu), kRecStride, (unsigned long long*)L.eigen_fail};
+  SS_STAMP(0);
   int ierr;
   if (NREG == 1 || g.veg_fraction <= L.cfg.min_vegetation_fraction) {
     // clear-sky region only: (1:ns, 1:1)
