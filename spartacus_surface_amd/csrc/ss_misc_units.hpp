@@ -118,6 +118,12 @@ SS_HD void zero_unit(const Inputs& in, const FluxDev& f, int nspec, int col) {
 //   a = fa * a,  b = fb * b  (in place; sunlit fractions are not scaled),
 //   sum = a + b   (a member missing in an operand counts as zero).
 struct ScaleSumLaunch {
+  static constexpr int kMaxMembers = 16;   // members of one shape class (16 of shape (nspec, ntotlay))
+  // members compacted per kind (filled by compact()): nm[kind] triplets
+  double* ma[4][kMaxMembers];
+  double* mb[4][kMaxMembers];
+  double* ms[4][kMaxMembers];
+  int nm[4];
   FluxDev a, b, sum;
   const double* fa;        // (nspec, ncol) factor of a, nullptr = a is not scaled
   const double* fb;        // (nspec, ncol) factor of b, nullptr = b is not scaled
@@ -126,6 +132,21 @@ struct ScaleSumLaunch {
   long col0, ncols;        // column range (0-based first, count)
   long lay0, nlays;        // packed layer range
 };
+
+// Group the members by shape class so that the kernel's loop over them is dense
+// (all loads of a thread are then issued back to back)
+inline void scale_sum_compact(ScaleSumLaunch& S) {
+  for (int k = 0; k < 4; ++k) S.nm[k] = 0;
+  for (int F = 0; F < F_NFIELDS; ++F) {
+    if (!S.a.f[F] && !S.b.f[F] && !S.sum.f[F]) continue;
+    const int k = flux_field_shape(F);
+    if (S.nm[k] >= ScaleSumLaunch::kMaxMembers) continue;   // cannot happen: 16 is the largest class
+    const int i = S.nm[k]++;
+    S.ma[k][i] = S.a.f[F];
+    S.mb[k][i] = S.b.f[F];
+    S.ms[k][i] = S.sum.f[F];
+  }
+}
 
 // kind 0: (band, column) elements of every (nspec, ncol) member;
 // kind 1: (band, layer) elements of every (nspec, ntotlay) member;
@@ -165,43 +186,55 @@ SS_HD void scale_sum_unit(const ScaleSumLaunch& S, int kind, long i) {
     if (S.fb) { if (in0) fb0 = S.fb[f0]; if (in1) fb1 = S.fb[f1]; }
   }
   const bool both = in0 && in1;
-  for (int F = 0; F < F_NFIELDS; ++F) {
-    if (flux_field_shape(F) != kind) continue;
-    double* pa = S.a.f[F];
-    double* pb = S.b.f[F];
-    double* ps = S.sum.f[F];
-    RecPair va = {0.0, 0.0}, vb = {0.0, 0.0};
-    if (pa) {
-      if (both) va = *reinterpret_cast<const RecPair*>(pa + e0);
-      else if (in0) va.x = pa[e0];
-      else va.y = pa[e0 + 1];
-      if (scaled && S.fa) {
-        va.x = fa0 * va.x;
-        va.y = fa1 * va.y;
-        if (both) *reinterpret_cast<RecPair*>(pa + e0) = va;
-        else if (in0) pa[e0] = va.x;
-        else pa[e0 + 1] = va.y;
+  const int nm = S.nm[kind];
+  // loads of all members first, then the arithmetic and the stores
+  RecPair va[ScaleSumLaunch::kMaxMembers], vb[ScaleSumLaunch::kMaxMembers];
+  SS_UNROLL_FULL
+  for (int m = 0; m < ScaleSumLaunch::kMaxMembers; ++m) {
+    va[m].x = va[m].y = vb[m].x = vb[m].y = 0.0;
+    if (m < nm) {
+      const double* pa = S.ma[kind][m];
+      const double* pb = S.mb[kind][m];
+      if (pa) {
+        if (both) va[m] = *reinterpret_cast<const RecPair*>(pa + e0);
+        else if (in0) va[m].x = pa[e0];
+        else va[m].y = pa[e0 + 1];
+      }
+      if (pb) {
+        if (both) vb[m] = *reinterpret_cast<const RecPair*>(pb + e0);
+        else if (in0) vb[m].x = pb[e0];
+        else vb[m].y = pb[e0 + 1];
       }
     }
-    if (pb) {
-      if (both) vb = *reinterpret_cast<const RecPair*>(pb + e0);
-      else if (in0) vb.x = pb[e0];
-      else vb.y = pb[e0 + 1];
-      if (scaled && S.fb) {
-        vb.x = fb0 * vb.x;
-        vb.y = fb1 * vb.y;
-        if (both) *reinterpret_cast<RecPair*>(pb + e0) = vb;
-        else if (in0) pb[e0] = vb.x;
-        else pb[e0 + 1] = vb.y;
+  }
+  SS_UNROLL_FULL
+  for (int m = 0; m < ScaleSumLaunch::kMaxMembers; ++m) {
+    if (m < nm) {
+      double* pa = S.ma[kind][m];
+      double* pb = S.mb[kind][m];
+      double* ps = S.ms[kind][m];
+      if (pa && scaled && S.fa) {
+        va[m].x = fa0 * va[m].x;
+        va[m].y = fa1 * va[m].y;
+        if (both) *reinterpret_cast<RecPair*>(pa + e0) = va[m];
+        else if (in0) pa[e0] = va[m].x;
+        else pa[e0 + 1] = va[m].y;
       }
-    }
-    if (ps) {
-      RecPair vs;
-      vs.x = va.x + vb.x;
-      vs.y = va.y + vb.y;
-      if (both) *reinterpret_cast<RecPair*>(ps + e0) = vs;
-      else if (in0) ps[e0] = vs.x;
-      else ps[e0 + 1] = vs.y;
+      if (pb && scaled && S.fb) {
+        vb[m].x = fb0 * vb[m].x;
+        vb[m].y = fb1 * vb[m].y;
+        if (both) *reinterpret_cast<RecPair*>(pb + e0) = vb[m];
+        else if (in0) pb[e0] = vb[m].x;
+        else pb[e0 + 1] = vb[m].y;
+      }
+      if (ps) {
+        RecPair vs;
+        vs.x = va[m].x + vb[m].x;
+        vs.y = va[m].y + vb[m].y;
+        if (both) *reinterpret_cast<RecPair*>(ps + e0) = vs;
+        else if (in0) ps[e0] = vs.x;
+        else ps[e0 + 1] = vs.y;
+      }
     }
   }
 }

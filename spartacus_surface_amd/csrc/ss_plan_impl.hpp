@@ -744,6 +744,7 @@ class Plan {
       S.ncols = iendcol - istartcol + 1;
       S.lay0 = lay_first;
       S.nlays = lay_count;
+      scale_sum_compact(S);
       Backend::launch_scale_sum(S, timers);
     };
     if (cfg.do_sw) {
