@@ -2,7 +2,7 @@
 # usage (GPU box): tools/pmc_icache.sh TAG -> instruction-fetch counters per kernel
 tag=${1:-main}
 export TMPDIR=/tmp
-P="python bench.py --steps 1 --warmup 0 --columns 200000 --no-cpu-baseline"
+P="python bench.py --steps 1 --warmup 0 --columns 200000 --no-extras"
 mkdir -p gpurun_out/pmc_$tag
 timeout -k 10 200 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES SQ_WAVES --output-format csv -d gpurun_out/pmc_$tag/p5 -- $P > gpurun_out/pmc_$tag/p5.log 2>&1 || { tail -5 gpurun_out/pmc_$tag/p5.log; exit 1; }
 python - "$tag" <<'PY'
