@@ -1,7 +1,20 @@
 import csv, glob, collections, sys, re
+
+def newest_per_pass(root):
+    """The newest counter file of every pass directory (gpurun merges new files
+    next to those of earlier runs of the same tag)."""
+    import os
+    out = []
+    for d in sorted(glob.glob(root + "/p*")):
+        fs = glob.glob(d + "/*/*_counter_collection.csv")
+        if fs:
+            out.append(max(fs, key=os.path.getmtime))
+    return out
+
+
 for v in sys.argv[1:]:
     agg = collections.defaultdict(dict)
-    for f in glob.glob("gpurun_out/pmc_%s/p*/*/*_counter_collection.csv" % v):
+    for f in newest_per_pass("gpurun_out/pmc_%s" % v):
         for r in csv.DictReader(open(f)):
             m = re.search(r"(k_\w+<[^>]+>)", r["Kernel_Name"])
             if not m: continue

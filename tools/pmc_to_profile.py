@@ -13,13 +13,26 @@ import json
 import re
 import sys
 
+def newest_per_pass(root):
+    """The newest counter file of every pass directory (gpurun merges new files
+    next to those of earlier runs of the same tag)."""
+    import os
+    out = []
+    for d in sorted(glob.glob(root + "/p*")):
+        fs = glob.glob(d + "/*/*_counter_collection.csv")
+        if fs:
+            out.append(max(fs, key=os.path.getmtime))
+    return out
+
+
+
 tag, ncol = sys.argv[1], int(sys.argv[2])
 FAMILY = {("k_layer", "false"): "sw_layer", ("k_column", "false"): "sw_column",
           ("k_down", "false"): "sw_down", ("k_down", "true"): "lw_down",
           ("k_layer", "true"): "lw_layer", ("k_column", "true"): "lw_column"}
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 meta = {}
-for f in glob.glob("gpurun_out/pmc_%s/p*/*/*_counter_collection.csv" % tag):
+for f in newest_per_pass("gpurun_out/pmc_%s" % tag):
     for r in csv.DictReader(open(f)):
         m = re.search(r"(k_\w+)<([^>]+)>", r["Kernel_Name"])
         if not m:
