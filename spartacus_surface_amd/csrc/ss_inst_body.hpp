@@ -96,7 +96,11 @@ void SS_INST_NAME(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev) {
   switch (ns) {
     case 1: launch_ns<1>(L, stream, ev); break;
     case 2: launch_ns<2>(L, stream, ev); break;
+    case 3: launch_ns<3>(L, stream, ev); break;
     case 4: launch_ns<4>(L, stream, ev); break;
+    case 5: launch_ns<5>(L, stream, ev); break;
+    case 6: launch_ns<6>(L, stream, ev); break;
+    case 7: launch_ns<7>(L, stream, ev); break;
     case 8: launch_ns<8>(L, stream, ev); break;
     default: break;
   }

@@ -60,7 +60,7 @@ struct ColumnClass {
 };
 
 inline bool key_supported(const ClassKey& k) {
-  const bool ns_ok = (k.ns == 1 || k.ns == 2 || k.ns == 4 || k.ns == 8);
+  const bool ns_ok = (k.ns >= 1 && k.ns <= 8);
   const bool nreg_ok = k.urban ? (k.nreg >= 1 && k.nreg <= 3) : (k.nreg == 2 || k.nreg == 3);
   return ns_ok && nreg_ok;
 }
@@ -83,7 +83,11 @@ inline int col_nelem(bool lw, const ClassKey& k) {
   switch (ns) {                                             \
     case 1: { constexpr int NS_ = 1; CALL(URB, NREG, NS_); } break; \
     case 2: { constexpr int NS_ = 2; CALL(URB, NREG, NS_); } break; \
+    case 3: { constexpr int NS_ = 3; CALL(URB, NREG, NS_); } break; \
     case 4: { constexpr int NS_ = 4; CALL(URB, NREG, NS_); } break; \
+    case 5: { constexpr int NS_ = 5; CALL(URB, NREG, NS_); } break; \
+    case 6: { constexpr int NS_ = 6; CALL(URB, NREG, NS_); } break; \
+    case 7: { constexpr int NS_ = 7; CALL(URB, NREG, NS_); } break; \
     case 8: { constexpr int NS_ = 8; CALL(URB, NREG, NS_); } break; \
     default: break;                                         \
   }

@@ -135,3 +135,24 @@ def all_cases(rami5="all"):
                 c["rami5/" + tag] = (lambda s=scene, i=ill, b=bs: rami5_case(s, i, b))
     c["single_layer/sp"] = lambda: single_layer_case(2)
     return c
+
+
+# ---- beyond the reference's own "make test": the same inputs with the stream
+# counts its Makefiles never select (3, 5, 6, 7 per hemisphere), so that every
+# compiled (regions, streams) instance has a golden vector from the reference ----
+def extra_cases():
+    c = {}
+
+    def urban_streams(n):
+        d = os.path.join(TEST, "urban")
+        nam = inputs.change_namelist(_nam(os.path.join(d, "config.nam")),
+                                     n_stream_sw_urban=n, n_stream_lw_urban=n)
+        return _build(nam, os.path.join(d, "russell_square.nc"), replicate=inputs.COS_SZA_46[::9])
+
+    # (test/simple's forest column is no use here: with 5+ streams the reference's
+    # own longwave result for it is NaN / an emissivity of 2.7)
+    for n in (3, 5, 6, 7):
+        c["extra/urban-%dstream" % n] = (lambda n=n: urban_streams(n))
+    for t in ("vis-snw-0.3-1-3", "vis-snw-0.3-2-3", "vis-snw-0.3-1-5", "vis-snw-0.3-2-6", "vis-snw-0.3-1-7"):
+        c["extra/rami4pilps-" + t] = (lambda t=t: rami4pilps_case(t))
+    return c

@@ -3,7 +3,8 @@
 Run in the build container (needs /root/reference for the test inputs and the
 compiled reference in oracle/_ref):
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py            # the reference's own test runs
+    python tests/golden/make_golden.py --extra    # + stream counts its tests never select (tests/cases.py)
 
 For every run of the reference's own `make test` that exercises the hot path
 (tests/cases.py) this freezes the solver inputs and the reference's fp64
@@ -26,7 +27,8 @@ def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
     checker.build()
     total = 0
-    for name, build in cases.all_cases(rami5="subset").items():
+    todo = cases.extra_cases() if "--extra" in sys.argv else cases.all_cases(rami5="subset")
+    for name, build in todo.items():
         case = build()
         outputs, _ = checker.run_ref(case["config"], case["canopy"], case["sw"], case["lw"],
                                      want_profiles=True,

@@ -21,7 +21,10 @@ CASES = ["simple__test_surfaces", "simple__test_surfaces_1stream", "simple__test
          "simple__test_nearly_empty_layers", "simple__test_overhang", "simple__test_noscat",
          "simple__test_closed", "single_layer__sp", "urban__1stream", "urban__2stream",
          "urban__4stream", "urban__single", "rami4pilps__vis-med-0.3", "rami4pilps__vis-snw-0.3-2-4",
-         "rami5__HET07_JPS_SUM-56-direct"]
+         "rami5__HET07_JPS_SUM-56-direct",
+         # stream counts beyond the reference's own tests (tests/cases.py: extra_cases)
+         "extra__urban-3stream", "extra__urban-5stream", "extra__urban-6stream",
+         "extra__rami4pilps-vis-snw-0.3-2-3", "extra__rami4pilps-vis-snw-0.3-1-7"]
 
 
 def _available():
