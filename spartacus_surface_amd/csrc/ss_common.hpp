@@ -62,6 +62,7 @@ struct LG {
   double weight[kDevMaxStreams];
   double hweight[kDevMaxStreams];
   double vweight[kDevMaxStreams];
+  double sqrt_wmu[kDevMaxStreams];   // sqrt(weight * mu): stream part of the symmetrising scaling (ss_eigen_sym.hpp)
   double vadjustment;
   double vadjustment2;
 };

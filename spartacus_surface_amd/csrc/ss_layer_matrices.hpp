@@ -26,6 +26,7 @@
 #include "ss_common.hpp"
 #include "ss_linalg.hpp"
 #include "ss_eigen.hpp"
+#include "ss_eigen_sym.hpp"
 
 namespace ss {
 
@@ -164,23 +165,29 @@ struct Diffuse {
 };
 
 template <int N, class PutR, class PutT>
-SS_HD int diffuse_part(const double* g1, const double* g2, double dz, Diffuse<N>& w,
+SS_HD int diffuse_part(const double* g1, const double* g2, const double* dscale, double dz, Diffuse<N>& w,
                        const PutR& putR, const PutT& putT, unsigned long long* stamps = nullptr,
                        int stamp0 = 0) {
   SS_STAMP_DECL(stamps);
   double GD[N * N], P[N * N], X[N * N], ev[N];
-  int ierr;
-  {
+  int ierr = -1;
+  SS_UNROLL_NN(N)
+  for (int k = 0; k < N * N; ++k) GD[k] = g1[k] - g2[k];
+  SS_STAMP(stamp0);
+  // eigen-decomposition of (G1 - G2)(G1 + G2): through its hidden symmetry where
+  // the register-resident solver exists (ss_eigen_sym.hpp), else - or when the
+  // structure is not there numerically - with the general solver of the reference
+  if constexpr (N >= 3 && N <= SS_UNROLL_MAX) {
+    if (dscale) ierr = eigen_decomposition_gamma_sym<N>(GD, g2, dscale, ev, X);
+    if (ierr >= 0 && !sym_spectrum_is_well_graded<N>(ev)) ierr = -1;
+  }
+  if (ierr < 0) {
     double GS[N * N];
     SS_UNROLL_NN(N)
-    for (int k = 0; k < N * N; ++k) {
-      GD[k] = g1[k] - g2[k];
-      GS[k] = g1[k] + g2[k];
-    }
+    for (int k = 0; k < N * N; ++k) GS[k] = g1[k] + g2[k];
     mat_mul<N, N, N>(GD, GS, P);
+    ierr = eigen_decomposition_real<N>(P, ev, X);
   }
-  SS_STAMP(stamp0);
-  ierr = eigen_decomposition_real<N>(P, ev, X);
   SS_STAMP(stamp0 + 1);
   SS_UNROLL_N(N)
   for (int j = 0; j < N; ++j) {
@@ -238,7 +245,8 @@ SS_HD int diffuse_part(const double* g1, const double* g2, double dz, Diffuse<N>
 // offset, R0 = region offset) of the full (NF, DF) record.
 template <int NF, int DF, int N, int D, int I0, int R0>
 SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
-                           const double* g3, double dz, const RecWriter& w) {
+                           const double* g3, const double* dsc0, const double* dsc, double dz,
+                           const RecWriter& w) {
   using Rec = SwRec<NF, DF>;
   SS_STAMP_DECL(w.stamps);
   int ierr = 0;
@@ -285,7 +293,16 @@ SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
 
   SS_STAMP(1);
   // Section 3 (:223-229): E = G0 diag(exp(mu dz)) G0^-1
-  ierr += eigen_decomposition_real<D>(g0, mu, G0);
+  {
+    // Gamma0 is symmetric after scaling with sqrt(region fraction)
+    int rc = -1;
+    if constexpr (D >= 3 && D <= SS_UNROLL_MAX) {
+      if (dsc0) rc = eigen_decomposition_scaled_sym<D>(g0, dsc0, mu, G0);
+      if (rc >= 0 && !sym_spectrum_is_well_graded<D>(mu)) rc = -1;
+    }
+    if (rc < 0) rc = eigen_decomposition_real<D>(g0, mu, G0);
+    ierr += rc;
+  }
   {
     double LU0[D * D], t[D * D];
     mat_copy<D, D>(G0, LU0);
@@ -338,7 +355,7 @@ SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
   // Sections 1-2: diffuse R, T
   Diffuse<N> df;
   ierr += diffuse_part<N>(
-      g1, g2, dz, df,
+      g1, g2, dsc, dz, df,
       [&](const double* R) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::R, R); },
       [&](const double* T) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::T, T); }, w.stamps, 3);
   SS_STAMP(20);   // (re-arm)
@@ -398,8 +415,8 @@ SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
 
 // calc_matrices_lw_eig for an N sub-problem embedded at stream offset I0.
 template <int NF, int N, int I0>
-SS_HD int calc_matrices_lw(const double* g1, const double* g2, const double* b, double dz,
-                           const RecWriter& w) {
+SS_HD int calc_matrices_lw(const double* g1, const double* g2, const double* b, const double* dsc,
+                           double dz, const RecWriter& w) {
   using Rec = LwRec<NF>;
   SS_STAMP_DECL(w.stamps);
   // Section 3 (:178-195): inv_gamma_b (first, while only the Gamma matrices are live)
@@ -422,7 +439,7 @@ SS_HD int calc_matrices_lw(const double* g1, const double* g2, const double* b, 
   SS_STAMP(12);
   Diffuse<N> df;
   int ierr = diffuse_part<N>(
-      g1, g2, dz, df,
+      g1, g2, dsc, dz, df,
       [&](const double* R) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::R, R); },
       [&](const double* T) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::T, T); }, w.stamps, 13);
   SS_STAMP(20);   // (re-arm)

@@ -23,6 +23,7 @@
 #pragma once
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -467,6 +468,7 @@ class Plan {
       l.weight[i] = on ? g.weight[i] : 0.0;
       l.hweight[i] = on ? g.hweight[i] : 0.0;
       l.vweight[i] = on ? g.vweight[i] : 0.0;
+      l.sqrt_wmu[i] = on ? std::sqrt(g.weight[i] * g.mu[i]) : 1.0;
     }
     l.vadjustment = g.vadjustment;
     l.vadjustment2 = g.vadjustment2;

@@ -172,6 +172,15 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay) {
     }
   }
 
+  // scaling that makes the Gamma matrices symmetric (ss_eigen_sym.hpp)
+  double dsc[N];
+  SS_UNROLL_FULL
+  for (int r = 0; r < NREG; ++r) {
+    const double dr = sqrt(p.frac[r]);
+    SS_UNROLL_FULL
+    for (int js = 0; js < NS; ++js) dsc[js + r * NS] = dr * lg.sqrt_wmu[js];
+  }
+
   RecWriter w{L.lay + rec_base(jlay, L.maxlay, Rec::NELEM, cu), kRecStride, (unsigned long long*)L.eigen_fail};
   SS_STAMP(10);
   int ierr;
@@ -179,16 +188,16 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay) {
     double s1[NS * NS], s2[NS * NS];
     get_block<N, NS, NS, 0, 0>(g1, s1);
     get_block<N, NS, NS, 0, 0>(g2, s2);
-    ierr = calc_matrices_lw<N, NS, 0>(s1, s2, b, p.g.dz, w);
+    ierr = calc_matrices_lw<N, NS, 0>(s1, s2, b, dsc, p.g.dz, w);
   } else if (p.frac[0] <= L.cfg.min_vegetation_fraction) {
     constexpr int NV = (NREG > 1) ? (NREG - 1) * NS : NS;
     constexpr int IV = (NREG > 1) ? NS : 0;
     double s1[NV * NV], s2[NV * NV];
     get_block<N, NV, NV, IV, IV>(g1, s1);
     get_block<N, NV, NV, IV, IV>(g2, s2);
-    ierr = calc_matrices_lw<N, NV, IV>(s1, s2, b + IV, p.g.dz, w);
+    ierr = calc_matrices_lw<N, NV, IV>(s1, s2, b + IV, dsc + IV, p.g.dz, w);
   } else {
-    ierr = calc_matrices_lw<N, N, 0>(g1, g2, b, p.g.dz, w);
+    ierr = calc_matrices_lw<N, N, 0>(g1, g2, b, dsc, p.g.dz, w);
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ierr != 0 && L.eigen_fail) atomicAdd(L.eigen_fail, 1ULL);

@@ -164,6 +164,15 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay) {
     }
   }
 
+  // scaling that makes the Gamma matrices symmetric (ss_eigen_sym.hpp)
+  double dsc0[D], dsc[N];
+  SS_UNROLL_FULL
+  for (int r = 0; r < NREG; ++r) {
+    dsc0[r] = sqrt(frac[r]);
+    SS_UNROLL_FULL
+    for (int js = 0; js < NS; ++js) dsc[js + r * NS] = dsc0[r] * L.lg.sqrt_wmu[js];
+  }
+
   // ---- layer matrices, 3-way branch (forest :408-455, urban :520-583) ----
   RecWriter w{L.lay + rec_base(jlay, L.maxlay, Rec::NELEM, cu), kRecStride, (unsigned long long*)L.eigen_fail};
   SS_STAMP(0);
@@ -175,7 +184,7 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay) {
     get_block<N, NS, NS, 0, 0>(g1, s1);
     get_block<N, NS, NS, 0, 0>(g2, s2);
     get_block<N, NS, 1, 0, 0>(g3, s3);
-    ierr = calc_matrices_sw<N, D, NS, 1, 0, 0>(s0, s1, s2, s3, g.dz, w);
+    ierr = calc_matrices_sw<N, D, NS, 1, 0, 0>(s0, s1, s2, s3, dsc0, dsc, g.dz, w);
   } else if (frac[0] <= L.cfg.min_vegetation_fraction) {
     // vegetated regions only: (ns+1:n, 2:nreg)
     constexpr int NV = (NREG > 1) ? (NREG - 1) * NS : NS;
@@ -187,9 +196,9 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay) {
     get_block<N, NV, NV, IV, IV>(g1, s1);
     get_block<N, NV, NV, IV, IV>(g2, s2);
     get_block<N, NV, DV, IV, RV>(g3, s3);
-    ierr = calc_matrices_sw<N, D, NV, DV, IV, RV>(s0, s1, s2, s3, g.dz, w);
+    ierr = calc_matrices_sw<N, D, NV, DV, IV, RV>(s0, s1, s2, s3, dsc0 + RV, dsc + IV, g.dz, w);
   } else {
-    ierr = calc_matrices_sw<N, D, N, D, 0, 0>(g0, g1, g2, g3, g.dz, w);
+    ierr = calc_matrices_sw<N, D, N, D, 0, 0>(g0, g1, g2, g3, dsc0, dsc, g.dz, w);
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ierr != 0 && L.eigen_fail) atomicAdd(L.eigen_fail, 1ULL);
