@@ -200,9 +200,11 @@ SS_HD int sym_tridiagonal_ql(double* d, double* e, double* z) {
 // D^-1 A D = -C (C symmetric positive definite) and D^-1 G2 D symmetric.
 // Returns 0 on success; -1 when the structure is not there (the caller then
 // uses the general solver); > 0 when the QL iteration did not converge.
+// ainv_x (N x N) receives A^-1 X = -D L^-T Y, which the caller needs next and
+// which costs one triangular solve here instead of an LU factorisation of A.
 template <int N>
 SS_HD int eigen_decomposition_gamma_sym(const double* A, const double* G2, const double* dscale,
-                                        double* eigenvalue, double* eigenvector) {
+                                        double* eigenvalue, double* eigenvector, double* ainv_x) {
   double rd[N];
   SS_UNROLL_FULL
   for (int i = 0; i < N; ++i) {
@@ -279,7 +281,7 @@ SS_HD int eigen_decomposition_gamma_sym(const double* A, const double* G2, const
   double e[N];
   sym_tridiagonalise<N>(K, eigenvalue, e);
   const int ierr = sym_tridiagonal_ql<N>(eigenvalue, e, K);
-  // eigenvectors of P: X = D L Y
+  // eigenvectors of P: X = D L Y;   A^-1 X = -D L^-T Y (back-substitution with L^T)
   SS_UNROLL_FULL
   for (int j = 0; j < N; ++j) {
     SS_UNROLL_FULL
@@ -288,6 +290,15 @@ SS_HD int eigen_decomposition_gamma_sym(const double* A, const double* G2, const
       SS_UNROLL_FULL
       for (int k = 0; k <= i; ++k) s += SS_E(C, i, k, N) * SS_E(K, k, j, N);
       SS_E(eigenvector, i, j, N) = dscale[i] * s;
+    }
+    double v[N];
+    SS_UNROLL_FULL
+    for (int i = N - 1; i >= 0; --i) {
+      double s = SS_E(K, i, j, N);
+      SS_UNROLL_FULL
+      for (int k = i + 1; k < N; ++k) s -= SS_E(C, k, i, N) * v[k];
+      v[i] = s * rl[i];
+      SS_E(ainv_x, i, j, N) = -dscale[i] * v[i];
     }
   }
   return ierr;

@@ -178,15 +178,23 @@ SS_HD int diffuse_part(const double* g1, const double* g2, const double* dscale,
   // the register-resident solver exists (ss_eigen_sym.hpp), else - or when the
   // structure is not there numerically - with the general solver of the reference
   if constexpr (N >= 3 && N <= SS_UNROLL_MAX) {
-    if (dscale) ierr = eigen_decomposition_gamma_sym<N>(GD, g2, dscale, ev, X);
+    if (dscale) ierr = eigen_decomposition_gamma_sym<N>(GD, g2, dscale, ev, X, P);
     if (ierr >= 0 && !sym_spectrum_is_well_graded<N>(ev)) ierr = -1;
   }
+#if defined(SS_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+  // profiling builds: slots 30 / 31 count the units that took the symmetric / the general solver
+  if (stamps && N >= 3 && N <= SS_UNROLL_MAX) atomicAdd(stamps + 1 + (ierr < 0 ? 30 : 29), 1ULL);
+#endif
   if (ierr < 0) {
     double GS[N * N];
     SS_UNROLL_NN(N)
     for (int k = 0; k < N * N; ++k) GS[k] = g1[k] + g2[k];
     mat_mul<N, N, N>(GD, GS, P);
     ierr = eigen_decomposition_real<N>(P, ev, X);
+    // P = GD^-1 X (the symmetric route returns it from its Cholesky factor)
+    lu_factor<N>(GD);
+    mat_copy<N, N>(X, P);
+    lu_solve_mat<N, N>(GD, P);
   }
   SS_STAMP(stamp0 + 1);
   SS_UNROLL_N(N)
@@ -194,10 +202,7 @@ SS_HD int diffuse_part(const double* g1, const double* g2, const double* dscale,
     w.lam[j] = sqrt(ss_max(0.0, ev[j]));
     w.e[j] = exp(-w.lam[j] * dz);
   }
-  // tmp = -(GD^-1 X) diag(lam);  G1 = X + tmp, G2 = X - tmp
-  lu_factor<N>(GD);
-  mat_copy<N, N>(X, P);
-  lu_solve_mat<N, N>(GD, P);
+  // tmp = -(GD^-1 X) diag(lam);  G1 = X + tmp, G2 = X - tmp   (P = GD^-1 X)
   SS_UNROLL_N(N)
   for (int j = 0; j < N; ++j) {
     SS_UNROLL_N(N)

@@ -39,9 +39,9 @@ int check(int ncase, unsigned seed) {
       for (int k = 0; k < N; ++k) s += A[i + k * N] * (A[k + j * N] + 2 * G2[k + j * N]);
       P[i + j * N] = s;
     }
-    double v1[N], x1[N * N], v2[N], x2[N * N];
+    double v1[N], x1[N * N], v2[N], x2[N * N], ax[N * N];
     ss::eigen_decomposition_real_dynamic<N>(P, v1, x1);
-    int rc = ss::eigen_decomposition_gamma_sym<N>(A, G2, d, v2, x2);
+    int rc = ss::eigen_decomposition_gamma_sym<N>(A, G2, d, v2, x2, ax);
     if (rc != 0) { if (bad < 3) printf("N=%d case %d rc %d\n", N, c, rc); ++bad; continue; }
     double s1[N], s2[N];
     for (int i = 0; i < N; ++i) { s1[i] = v1[i]; s2[i] = v2[i]; }
@@ -58,6 +58,14 @@ int check(int ncase, unsigned seed) {
         xn = std::max(xn, fabs(x2[i + j * N]));
       }
       worst_res = std::max(worst_res, rn / (scale * xn));
+      // A (A^-1 X) = X
+      double an = 0;
+      for (int i = 0; i < N; ++i) {
+        double s = 0;
+        for (int k = 0; k < N; ++k) s += A[i + k * N] * ax[k + j * N];
+        an = std::max(an, fabs(s - x2[i + j * N]));
+      }
+      worst_res = std::max(worst_res, an / xn * 1e-3);   // (conditioning of A up to ~1e3 here)
     }
   }
   printf("N=%d: %d cases, %d failures, worst eigenvalue diff %.2e, worst residual %.2e\n", N, ncase, bad,
