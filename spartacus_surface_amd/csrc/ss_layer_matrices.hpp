@@ -271,21 +271,21 @@ SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
       for (int k = 0; k < D * D; ++k) idir[k] = -g0i[k];
       put_embedded<DF, DF, D, D, R0, R0>(w, Rec::IDIR, idir);
     }
-    double LU1[N * N], g1i[N * N], g2i[N * N], t[N * N];
-    mat_copy<N, N>(g1, LU1);
-    lu_factor<N>(LU1);
-    mat_copy<N, N>(g2, t);
-    lu_solve_mat<N, N>(LU1, t);                 // g1^-1 g2
-    mat_mul<N, N, N>(g2, t, g2i);
-    SS_UNROLL_NN(N)
-    for (int k = 0; k < N * N; ++k) g2i[k] = g1[k] - g2i[k];
-    lu_factor<N>(g2i);
-    lu_invert<N>(g2i, g1i);                     // g1i = (g1 - g2 g1^-1 g2)^-1
-    lu_invert<N>(LU1, t);                       // g1^-1
-    mat_mul<N, N, N>(g2, t, LU1);               // g2 g1^-1
-    mat_mul<N, N, N>(g1i, LU1, g2i);            // g2i
-    SS_UNROLL_NN(N)
-    for (int k = 0; k < N * N; ++k) t[k] = g2i[k] - g1i[k];
+    // int_diff = g2i - g1i of the Schur inverse (radtool_schur.F90:45-51), with
+    //   g1i = (G1 - G2 G1^-1 G2)^-1,  g2i = g1i G2 G1^-1.
+    // Since G1 - G2 G1^-1 G2 = (G1 - G2) G1^-1 (G1 + G2), this is
+    //   g1i (G2 G1^-1 - I) = (G1 + G2)^-1 G1 (G1 - G2)^-1 (G2 - G1) G1^-1 = -(G1 + G2)^-1:
+    // one inverse instead of two inverses, two products and a solve.
+    double t[N * N];
+    {
+      double B[N * N];
+      SS_UNROLL_NN(N)
+      for (int k = 0; k < N * N; ++k) B[k] = g1[k] + g2[k];
+      lu_factor<N>(B);
+      lu_invert<N>(B, t);
+      SS_UNROLL_NN(N)
+      for (int k = 0; k < N * N; ++k) t[k] = -t[k];
+    }
     put_embedded<NF, NF, N, N, I0, I0>(w, Rec::IDIFF, t);      // int_diff = g2i - g1i
     // g3i = (g1i - g2i) (g3 g0i);  int_dir_diff = 2 g3i = -2 t (g3 g0i)
     double u[N * D], v[N * D];
@@ -425,21 +425,17 @@ SS_HD int calc_matrices_lw(const double* g1, const double* g2, const double* b, 
   using Rec = LwRec<NF>;
   SS_STAMP_DECL(w.stamps);
   // Section 3 (:178-195): inv_gamma_b (first, while only the Gamma matrices are live)
+  // (G1 - G2 G1^-1 G2) igb = (G2 G1^-1 - I) b  <=>  igb = -(G1 + G2)^-1 b  (same identity as
+  // for int_diff of the shortwave: G1 - G2 G1^-1 G2 = (G1 - G2) G1^-1 (G1 + G2))
   double igb[N];
   {
-    double LU1[N * N], K[N * N], M[N * N];
-    mat_copy<N, N>(g1, LU1);
-    lu_factor<N>(LU1);
-    lu_invert<N>(LU1, M);
-    mat_mul<N, N, N>(g2, M, K);                 // gamma2 gamma1^-1
-    mat_mul<N, N, N>(K, g2, M);
+    double B[N * N];
     SS_UNROLL_NN(N)
-    for (int k = 0; k < N * N; ++k) M[k] = g1[k] - M[k];
+    for (int k = 0; k < N * N; ++k) B[k] = g1[k] + g2[k];
+    lu_factor<N>(B);
     SS_UNROLL_N(N)
-    for (int jo = 0; jo < N; ++jo) SS_E(K, jo, jo, N) -= 1.0;
-    mat_vec<N, N>(K, b, igb);
-    lu_factor<N>(M);
-    lu_solve<N>(M, igb);
+    for (int i = 0; i < N; ++i) igb[i] = -b[i];
+    lu_solve<N>(B, igb);
   }
   SS_STAMP(12);
   Diffuse<N> df;
