@@ -164,12 +164,24 @@ struct Diffuse {
   double lam[N], e[N];
 };
 
-template <int N, class PutR, class PutT>
+// Optionally (ND > 0) also the particular solutions of the direct-beam sources
+// (sw_eig :231-253): for every direct eigenvalue mu and source s = srhs(:, jd)
+//   (G1 + mu) g3 + G2 g4 = -s,   G2 g3 + (G1 - mu) g4 = -s.
+// With p = g3 + g4, q = g3 - g4 the sum and the difference of the two read
+//   (P - mu^2) p = -2 (G1 - G2) s,   q = -mu (G1 - G2)^-1 p,   P = (G1 - G2)(G1 + G2),
+// so the eigen-decomposition P = X Lambda X^-1 that is needed anyway gives
+//   p = X c,  q = -mu ((G1 - G2)^-1 X) c,  c = -2 (Lambda - mu^2)^-1 X^-1 (G1 - G2) s
+// for three matrix-vector products per mu, where the reference factorises two
+// N x N matrices, inverts one and multiplies two per mu.  X^-1 (G1 - G2) s is
+// -(D^-2 X)^T s on the symmetric route and an LU solve with X on the general one.
+template <int N, int ND = 0, class PutR, class PutT>
 SS_HD int diffuse_part(const double* g1, const double* g2, const double* dscale, double dz, Diffuse<N>& w,
                        const PutR& putR, const PutT& putT, unsigned long long* stamps = nullptr,
-                       int stamp0 = 0) {
+                       int stamp0 = 0, const double* srhs = nullptr, const double* mu = nullptr,
+                       double* g3v = nullptr, double* g4v = nullptr) {
   SS_STAMP_DECL(stamps);
   double GD[N * N], P[N * N], X[N * N], ev[N];
+  double hc[N * (ND > 0 ? ND : 1)];   // X^-1 (G1 - G2) s, one column per direct eigenvalue
   int ierr = -1;
   SS_UNROLL_NN(N)
   for (int k = 0; k < N * N; ++k) GD[k] = g1[k] - g2[k];
@@ -180,6 +192,22 @@ SS_HD int diffuse_part(const double* g1, const double* g2, const double* dscale,
   if constexpr (N >= 3 && N <= SS_UNROLL_MAX) {
     if (dscale) ierr = eigen_decomposition_gamma_sym<N>(GD, g2, dscale, ev, X, P);
     if (ierr >= 0 && !sym_spectrum_is_well_graded<N>(ev)) ierr = -1;
+    if (ND > 0 && ierr >= 0) {
+      // X^-1 (G1 - G2) s = -(D^-2 X)^T s
+      double rd2[N];
+      SS_UNROLL_N(N)
+      for (int i = 0; i < N; ++i) rd2[i] = 1.0 / (dscale[i] * dscale[i]);
+      SS_UNROLL_N(ND)
+      for (int jd = 0; jd < ND; ++jd) {
+        SS_UNROLL_N(N)
+        for (int k = 0; k < N; ++k) {
+          double h = 0.0;
+          SS_UNROLL_N(N)
+          for (int i = 0; i < N; ++i) h -= SS_E(X, i, k, N) * (srhs[i + jd * N] * rd2[i]);
+          hc[k + jd * N] = h;
+        }
+      }
+    }
   }
 #if defined(SS_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
   // profiling builds: slots 30 / 31 count the units that took the symmetric / the general solver
@@ -191,10 +219,33 @@ SS_HD int diffuse_part(const double* g1, const double* g2, const double* dscale,
     for (int k = 0; k < N * N; ++k) GS[k] = g1[k] + g2[k];
     mat_mul<N, N, N>(GD, GS, P);
     ierr = eigen_decomposition_real<N>(P, ev, X);
+    if (ND > 0) {
+      // X^-1 ((G1 - G2) s) by an LU solve with X (GS is free: reuse it for LU(X))
+      mat_mul<N, N, (ND > 0 ? ND : 1)>(GD, srhs, hc);
+      mat_copy<N, N>(X, GS);
+      lu_factor<N>(GS);
+      lu_solve_mat<N, (ND > 0 ? ND : 1)>(GS, hc);
+    }
     // P = GD^-1 X (the symmetric route returns it from its Cholesky factor)
     lu_factor<N>(GD);
     mat_copy<N, N>(X, P);
     lu_solve_mat<N, N>(GD, P);
+  }
+  if (ND > 0) {
+    SS_UNROLL_N(ND)
+    for (int jd = 0; jd < ND; ++jd) {
+      double c[N], pv[N], qv[N];
+      SS_UNROLL_N(N)
+      for (int k = 0; k < N; ++k) c[k] = -2.0 * hc[k + jd * N] / (ev[k] - mu[jd] * mu[jd]);
+      mat_vec<N, N>(X, c, pv);
+      mat_vec<N, N>(P, c, qv);
+      SS_UNROLL_N(N)
+      for (int i = 0; i < N; ++i) {
+        const double q = -mu[jd] * qv[i];
+        g3v[i + jd * N] = 0.5 * (pv[i] + q);
+        g4v[i + jd * N] = 0.5 * (pv[i] - q);
+      }
+    }
   }
   SS_STAMP(stamp0 + 1);
   SS_UNROLL_N(N)
@@ -321,48 +372,19 @@ SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
     put_embedded<DF, DF, D, D, R0, R0>(w, Rec::EDIR, Ed);
   }
 
-  // Section 4 (:231-253): g3, g4 for each direct eigenvalue
-  {
-    double g3g0[N * D];
-    mat_mul<N, D, D>(g3, G0, g3g0);
-    SS_UNROLL_N(D)
-    for (int jd = 0; jd < D; ++jd) {
-      double LUd[N * N], K[N * N], M[N * N];
-      mat_copy<N, N>(g1, LUd);
-      SS_UNROLL_N(N)
-      for (int jo = 0; jo < N; ++jo) SS_E(LUd, jo, jo, N) += mu[jd];
-      lu_factor<N>(LUd);                       // gamma1_d = gamma1 + mu I
-      lu_invert<N>(LUd, M);
-      mat_mul<N, N, N>(g2, M, K);               // gamma2 gamma1_d^-1
-      mat_mul<N, N, N>(K, g2, M);
-      SS_UNROLL_NN(N)
-      for (int k = 0; k < N * N; ++k) M[k] = g1[k] - M[k];
-      SS_UNROLL_N(N)
-      for (int jo = 0; jo < N; ++jo) {
-        SS_E(M, jo, jo, N) -= mu[jd];
-        SS_E(K, jo, jo, N) -= 1.0;
-      }
-      double* g4c = g4v + jd * N;
-      double* g3c = g3v + jd * N;
-      mat_vec<N, N>(K, g3g0 + jd * N, g4c);
-      lu_factor<N>(M);
-      lu_solve<N>(M, g4c);
-      mat_vec<N, N>(g2, g4c, g3c);
-      SS_UNROLL_N(N)
-      for (int i = 0; i < N; ++i) g3c[i] = g3g0[jd * N + i] + g3c[i];
-      lu_solve<N>(LUd, g3c);
-      SS_UNROLL_N(N)
-      for (int i = 0; i < N; ++i) g3c[i] = -g3c[i];
-    }
-  }
+  // Section 4 (:231-253): the sources of the particular solutions g3, g4, one column
+  // per direct eigenvalue; solved inside diffuse_part from the eigen-decomposition
+  double g3g0[N * D];
+  mat_mul<N, D, D>(g3, G0, g3g0);
 
   SS_STAMP(2);
   // Sections 1-2: diffuse R, T
   Diffuse<N> df;
-  ierr += diffuse_part<N>(
+  ierr += diffuse_part<N, D>(
       g1, g2, dsc, dz, df,
       [&](const double* R) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::R, R); },
-      [&](const double* T) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::T, T); }, w.stamps, 3);
+      [&](const double* T) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::T, T); }, w.stamps, 3,
+      g3g0, mu, g3v, g4v);
   SS_STAMP(20);   // (re-arm)
 
   // direct_diffuse_part (:303-386) by block elimination (see header comment)
