@@ -259,7 +259,7 @@ def main():
 
     # two extra, untimed steps with strictly serial kernels (one stream): per-kernel
     # durations without the chunk overlap of the timed region
-    pipes = int(os.environ.get("SPARTACUS_PIPES", "2"))
+    pipes = int(os.environ.get("SPARTACUS_PIPES", "4"))
     serial_ms = None
     if pipes > 1 and not args.no_extras:
         plan.set_pipes(1)

@@ -285,8 +285,8 @@ int ss_plan_scale_and_sum(ss_plan *plan, const double *top_flux_dn_sw,
 int ss_plan_download_sums(ss_plan *plan, ss_flux *sw_flux, ss_flux *lw_flux);
 /* Number of concurrent HIP streams ("pipes") the next ss_plan_solve spreads its
  * chunk launches over: 1 = strictly serial kernels (what per-kernel profiling
- * wants), 2 (default, env SPARTACUS_PIPES) = the memory-bound column kernels of
- * one chunk overlap with the arithmetic-bound layer kernel of the next.  No
+ * wants), up to 4 (default 4, env SPARTACUS_PIPES) = the memory-bound column
+ * kernels of one chunk overlap with the arithmetic-bound layer kernels of others.  No
  * counterpart in the reference (its concurrency is the OpenMP block loop,
  * driver/spartacus_surface_driver.F90:206-233). */
 int ss_plan_set_pipes(ss_plan *plan, int32_t npipes);

@@ -137,7 +137,7 @@ class Plan {
   double* d_lay[kMaxPipes] = {};
   double* d_col[kMaxPipes] = {};
   size_t scratch_budget_bytes = 0;
-  static constexpr int kDefaultPipes = 2;
+  static constexpr int kDefaultPipes = 4;
   int pipes_wanted = kDefaultPipes;
   size_t lay_bytes = 0, col_bytes = 0;
   // slot 0: eigen failures of the last solve; the rest: section stamps of profiling builds
