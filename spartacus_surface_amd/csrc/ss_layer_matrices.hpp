@@ -4,9 +4,16 @@
 // with schur_invert_sw (radtool/radtool_schur.F90:32-53).
 //
 // Same mathematics as the reference (Hogan 2019 Eqs. 45-49, 56-59), re-ordered
-// for a register-resident lane:
-//  * the direct-beam particular solutions g3, g4 (sw_eig :231-253) are computed
-//    FIRST, while only the Gamma matrices are live;
+// for a register-resident lane and using structure the reference does not:
+//  * the eigen-decomposition of P = (G1 - G2)(G1 + G2) goes through the hidden
+//    symmetry of the Gamma matrices where it can (ss_eigen_sym.hpp), which also
+//    yields (G1 - G2)^-1 X from the Cholesky factor;
+//  * the direct-beam particular solutions g3, g4 (sw_eig :231-253) come from that
+//    eigen-decomposition ((P - mu^2) p = -2 (G1 - G2) s, diffuse_part) instead of
+//    two LU factorisations, an inverse and two products per direct eigenvalue;
+//  * int_diff = -(G1 + G2)^-1 and inv_gamma_b = -(G1 + G2)^-1 b by the identity
+//    G1 - G2 G1^-1 G2 = (G1 - G2) G1^-1 (G1 + G2) (radtool_schur.F90:45-51,
+//    lw_eig :178-195);
 //  * the (2n+d) x (2n+d) system of direct_diffuse_part (:303-386) is never
 //    formed: its matrix is block upper-triangular,
 //        [ G1   G2D  g3*e ]   [c1]   [0]
