@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -411,15 +412,37 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
   // (spartacus_surface_driver.F90:206-233); one device, one stream: serialise.
   std::lock_guard<std::mutex> lock(g_device_mutex);
   return guarded([&]() {
-    HipPlan plan;
     const bool profiles = (sw_norm_dir && sw_norm_dir->flux_dn_layer_top)
                           || (lw_internal && lw_internal->flux_dn_layer_top);
-    int r = plan.create(config, canopy, sw, lw, istartcol, iendcol, profiles ? 1 : 0);
-    if (r) { g_last_error = plan.error; return r; }
+    // A host model calls this entry once per time step with the same configuration and
+    // shapes: the plan (device mirrors, scratch: GiBs of hipMalloc) of the previous call is
+    // kept and only re-filled, unless SPARTACUS_NO_PLAN_CACHE is set.
+    static HipPlan* cached = nullptr;   // deliberately never destroyed at process exit (HIP may be gone)
+    static ss_config cached_cfg;
+    static int cached_dims[5] = {-1, -1, -1, -1, -1};
+    const int dims[5] = {canopy->ncol, canopy->ntotlay, istartcol, iendcol, profiles ? 1 : 0};
+    const bool reuse = cached && !std::getenv("SPARTACUS_NO_PLAN_CACHE")
+                       && std::memcmp(&cached_cfg, config, sizeof(ss_config)) == 0
+                       && std::memcmp(cached_dims, dims, sizeof(dims)) == 0;
+    int r;
+    if (reuse) {
+      r = cached->upload(canopy, sw, lw);
+    } else {
+      delete cached;
+      cached = new HipPlan;
+      cached->pipes_cap = 2;   // less scratch to allocate for what may be a one-shot call
+      r = cached->create(config, canopy, sw, lw, istartcol, iendcol, profiles ? 1 : 0);
+      cached_cfg = *config;
+      std::memcpy(cached_dims, dims, sizeof(dims));
+    }
+    HipPlan& plan = *cached;
+    if (r) { g_last_error = plan.error; delete cached; cached = nullptr; return r; }
     plan.upload_outputs(bc_out, sw_norm_dir, sw_norm_diff, lw_internal, lw_norm);
     r = plan.solve();
-    if (r) { g_last_error = plan.error; return r; }
-    return plan.download(bc_out, sw_norm_dir, sw_norm_diff, lw_internal, lw_norm);
+    if (r) { g_last_error = plan.error; delete cached; cached = nullptr; return r; }
+    r = plan.download(bc_out, sw_norm_dir, sw_norm_diff, lw_internal, lw_norm);
+    if (std::getenv("SPARTACUS_NO_PLAN_CACHE")) { delete cached; cached = nullptr; }
+    return r;
   });
 }
 

@@ -139,6 +139,7 @@ class Plan {
   size_t scratch_budget_bytes = 0;
   static constexpr int kDefaultPipes = 4;
   int pipes_wanted = kDefaultPipes;
+  int pipes_cap = kMaxPipes;     // set before create(): upper limit for this plan
   size_t lay_bytes = 0, col_bytes = 0;
   // slot 0: eigen failures of the last solve; the rest: section stamps of profiling builds
   static constexpr int kCounters = 32;
@@ -258,7 +259,7 @@ class Plan {
     const char* mb = std::getenv("SPARTACUS_SCRATCH_MB");
     scratch_budget_bytes = (mb ? (size_t)std::atol(mb) : (size_t)4096) << 20;
     const char* np = std::getenv("SPARTACUS_PIPES");
-    pipes_wanted = np ? std::max(1, std::atoi(np)) : kDefaultPipes;
+    pipes_wanted = std::min(pipes_cap, np ? std::max(1, std::atoi(np)) : kDefaultPipes);
 
     ensure("bc_out.sw_albedo", std::max<size_t>(1, (size_t)nsw * ncol));
     ensure("bc_out.sw_albedo_dir", std::max<size_t>(1, (size_t)nsw * ncol));
@@ -696,7 +697,9 @@ class Plan {
       const int shape = flux_field_shape(F);
       const int ns = (shape == 0 || shape == 1) ? nspec : 1;
       if (shape == 0 || shape == 2) { if (to_host) get_cols(name.c_str(), m[F], ns); else put_cols(name.c_str(), m[F], ns); }
-      else { if (to_host) get_lays(name.c_str(), m[F], ns); else put_lays(name.c_str(), m[F], ns); }
+      else if (to_host) get_lays(name.c_str(), m[F], ns);
+      // (per-layer members are not seeded from the host: every layer of every column of the
+      //  range is written by the solver or zeroed by the night kernel)
     }
   }
 
