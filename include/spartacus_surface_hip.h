@@ -220,10 +220,10 @@ typedef struct ss_flux {
  * calls are serialised per device inside the library.
  * The pointers are HOST pointers; the library stages them to HBM, runs the HIP
  * kernels on the current device and copies the results back.
- * --------------------------------------------------------------------------  * The device plan of the previous call is cached and re-filled when the
+ * The device plan of the previous call is cached and re-filled when the
  * configuration, the shapes and the column range are the same (a model calling
  * every time step); SPARTACUS_NO_PLAN_CACHE=1 disables that.
- */
+ * -------------------------------------------------------------------------- */
 int spartacus_radsurf_hip(const ss_config *config, const ss_canopy *canopy,
                           const ss_sw_spectral *sw, const ss_lw_spectral *lw,
                           ss_bc_out *bc_out, int32_t istartcol, int32_t iendcol,
