@@ -60,8 +60,8 @@ enum {
   SS_ERR_VEG_DISABLED = 4,       /* radsurf_urban_sw.F90:275-277              */
   SS_ERR_BAD_ARGUMENT = 5,
   SS_ERR_HIP = 6,                /* a HIP call failed; see ss_last_error()    */
-  SS_ERR_TILE_NOT_ON_DEVICE = 7  /* tile types 4,5: single-layer Harman path,
-                                    SURVEY.md section 8(f) rank 4 (next)      */
+  SS_ERR_TILE_NOT_ON_DEVICE = 7  /* no longer returned: tile types 4,5 are solved
+                                    on the device; value kept for ABI stability */
 };
 
 /* legendre_gauss_type (radtool/radtool_legendre_gauss.F90:25-48). */

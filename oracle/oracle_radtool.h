@@ -24,6 +24,7 @@
 typedef __float128 or_real;
 #define OR_SQRT sqrtq
 #define OR_EXP expq
+#define OR_ATAN atanq
 #define OR_FABS fabsq
 #define OR_FMAX fmaxq
 #define OR_COPYSIGN copysignq
@@ -33,6 +34,7 @@ typedef __float128 or_real;
 typedef double or_real;
 #define OR_SQRT sqrt
 #define OR_EXP exp
+#define OR_ATAN atan
 #define OR_FABS fabs
 #define OR_FMAX fmax
 #define OR_COPYSIGN copysign

@@ -1202,6 +1202,232 @@ static int simple_spectrum_lw(const ss_config *cfg, const ss_canopy *cp, const s
   return SS_OK;
 }
 
+/* ==========================================================================
+ * Single-layer "simple urban" tiles (types 4, 5): Harman et al. 2x2 problem
+ * with infinite-street or exponential view factors.
+ * ========================================================================== */
+
+/* calc_view_factors_inf (radsurf/radsurf_view_factor.F90:28-69); cos_sza <= 0
+ * means "direct part not requested" */
+static void view_factors_inf(or_real hw, or_real *vgs, or_real *vww, or_real cos_sza, or_real *vdg) {
+  *vgs = OR_SQRT(hw * hw + 1.0) - hw;
+  *vww = OR_SQRT(1.0 / (hw * hw) + 1.0) - 1.0 / hw;
+  if (vdg) {
+    or_real norm_x0 = (Pi * 0.5) * hw * OR_SQRT(1.0 / (cos_sza * cos_sza) - 1.0);
+    or_real y_over_w = OR_SQRT(OR_FMAX(norm_x0 * norm_x0 - 1.0, 0.0));
+    if (y_over_w > 0.0) *vdg = (2.0 / Pi) * (y_over_w - norm_x0 + OR_ATAN(1.0 / y_over_w));
+    else *vdg = 1.0 - 2.0 * norm_x0 / Pi;
+  }
+}
+
+/* calc_view_factors_exp (radsurf_view_factor.F90:75-136) */
+static void view_factors_exp(or_real hx, or_real *vgs, or_real *vww, or_real cos_sza, or_real *vdg) {
+  static const double weights[8] = {0.0506142681451884, 0.111190517226687, 0.156853322938944,
+                                    0.181341891689181,  0.181341891689181, 0.156853322938944,
+                                    0.111190517226687,  0.0506142681451884};
+  static const double nodes[8] = {0.0198550717512319, 0.101666761293187, 0.237233795041836,
+                                  0.408282678752175,  0.591717321247825, 0.762766204958164,
+                                  0.898333238706813,  0.980144928248768};
+  or_real hweight[8], vweight[8], sh = 0.0, sv = 0.0, a = 0.0, b = 0.0;
+  for (int k = 0; k < 8; ++k) sh += (or_real)weights[k] * nodes[k];
+  for (int k = 0; k < 8; ++k) hweight[k] = (or_real)weights[k] * nodes[k] / sh;
+  for (int k = 0; k < 8; ++k) vweight[k] = weights[k] * OR_SQRT(1.0 - (or_real)nodes[k] * nodes[k]);
+  for (int k = 0; k < 8; ++k) sv += vweight[k];
+  for (int k = 0; k < 8; ++k) vweight[k] = vweight[k] / sv;
+  for (int k = 0; k < 8; ++k) {
+    or_real tk = hx * OR_SQRT(1.0 / ((or_real)nodes[k] * nodes[k]) - 1.0);
+    or_real e = OR_EXP(-tk);
+    a += hweight[k] * e;
+    b += vweight[k] * (1.0 - e) / tk;
+  }
+  *vgs = a;
+  *vww = 1.0 - b;
+  if (vdg) *vdg = OR_EXP(-(hx * OR_SQRT(1.0 / (cos_sza * cos_sza) - 1.0)));
+}
+
+/* Geometry shared by the SW and LW variants
+ * (radsurf_simple_urban_sw.F90:124-152, _lw.F90:118-143) */
+typedef struct {
+  or_real vgs, vww, vwg, vgw, vdg, npw, bf, dz;
+} simple_geom;
+
+static void simple_urban_geometry(const ss_config *cfg, int infinite, const ss_canopy *cp, int ilay,
+                                  or_real cos_sza, int want_dir, simple_geom *g) {
+  const double zero = 0.0, one = 1.0;
+  or_real np[1], npw[1];
+  g->dz = cp->dz[ilay];
+  g->bf = cp->building_fraction[ilay];
+  or_calc_norm_perim_urban(cfg, 1, 1, cp->building_fraction + ilay, cp->building_scale + ilay,
+                           &zero, &one, &zero, np, npw);
+  g->npw = npw[0];
+  g->vdg = 0.0;
+  if (infinite) {
+    or_real street_width = 2.0 * (1.0 - g->bf) / g->npw;
+    view_factors_inf(g->dz / street_width, &g->vgs, &g->vww, cos_sza, want_dir ? &g->vdg : NULL);
+  } else {
+    or_real sep = Pi * (1.0 - g->bf) / g->npw;
+    view_factors_exp(g->dz / sep, &g->vgs, &g->vww, cos_sza, want_dir ? &g->vdg : NULL);
+  }
+  g->vwg = 0.5 * (1.0 - g->vww);
+  g->vgw = 1.0 - g->vgs;
+}
+
+/* simple_urban_sw (radsurf_simple_urban_sw.F90:28-294).  The reference indexes
+ * several (nspec,ncol) members with the LAYER index (e.g. :200, :255-257,
+ * :263-275); that is the same element whenever istartlay(icol) == icol - every
+ * column before it has exactly one layer - which is the only arrangement its
+ * own test (test/single_layer) uses.  This restatement uses the column index
+ * throughout.  top_albedo_diff/dir are never assigned by the reference
+ * (bc_out keeps its previous contents), so they are not touched here. */
+static void simple_urban_sw(const ss_config *cfg, int infinite, int nsw, int icol, int ilay,
+                            or_real cos_sza, const ss_canopy *cp, const ss_sw_spectral *sp,
+                            const double *galb, const double *galb_dir, ss_flux *fdir, ss_flux *fdiff) {
+  simple_geom g;
+  simple_urban_geometry(cfg, infinite, cp, ilay, cos_sza, 1, &g);
+  const or_real vdw = 1.0 - g.vdg, open = 1.0 - g.bf;
+  flux_zero(fdiff, icol, ilay, 1);
+  flux_zero(fdir, icol, ilay, 1);
+  for (int jb = 0; jb < nsw; ++jb) {
+    const size_t c = jb + (size_t)nsw * icol, l = jb + (size_t)nsw * ilay;
+    const or_real wall_albedo = sp->wall_albedo[l], roof_albedo = sp->roof_albedo[l];
+    const or_real ga = galb[jb], gad = galb_dir[jb];
+    or_real A[4], src[2], x[2], up;
+    E(A, 0, 0, 2) = 1.0;
+    E(A, 0, 1, 2) = -g.vwg * wall_albedo;
+    E(A, 1, 0, 2) = -g.vgw * ga;
+    E(A, 1, 1, 2) = 1.0 - g.vww * wall_albedo;
+    /* direct */
+    src[0] = 0.0;
+    src[1] = (vdw + gad * g.vdg * g.vgw) * open;
+    or_solve_vec(2, A, src, x);
+    {
+      const or_real gdd = g.vdg * open, gdn = gdd + x[0];
+      const or_real gnet = gdd * (1.0 - gad) + x[0] * (1.0 - ga);
+      const or_real wnet = x[1] * (1.0 - wall_albedo);
+      fdir->ground_dn_dir[c] = gdd;
+      fdir->ground_dn[c] = gdn;
+      fdir->ground_net[c] = gnet;
+      fdir->roof_in_dir[l] = g.bf;
+      fdir->roof_in[l] = g.bf;
+      fdir->roof_net[l] = g.bf * (1.0 - roof_albedo);
+      fdir->wall_in_dir[l] = vdw * open;
+      fdir->wall_in[l] = x[1];
+      fdir->wall_net[l] = wnet;
+      fdir->top_dn_dir[c] = 1.0;
+      fdir->top_dn[c] = 1.0;
+      up = (gdn - gnet) * g.vgs + (x[1] - wnet) * g.vwg;
+      fdir->top_net[c] = 1.0 - g.bf * roof_albedo - (gdn - gnet) * g.vgs - (x[1] - wnet) * g.vwg;
+      if (fdir->flux_dn_layer_top) {
+        fdir->flux_dn_dir_layer_top[l] = open;
+        fdir->flux_dn_layer_top[l] = open;
+        fdir->flux_up_layer_top[l] = up;
+        fdir->flux_dn_dir_layer_base[l] = gdd;
+        fdir->flux_dn_layer_base[l] = gdn;
+        fdir->flux_up_layer_base[l] = gdn - gnet;
+      }
+    }
+    /* diffuse */
+    src[0] = g.vgs * open;
+    src[1] = g.vgw * open;
+    or_solve_vec(2, A, src, x);
+    {
+      const or_real gdn = x[0], gnet = gdn * (1.0 - ga), wnet = x[1] * (1.0 - wall_albedo);
+      fdiff->ground_dn_dir[c] = 0.0;
+      fdiff->ground_dn[c] = gdn;
+      fdiff->ground_net[c] = gnet;
+      fdiff->roof_in[l] = g.bf;
+      fdiff->roof_net[l] = g.bf * (1.0 - roof_albedo);
+      fdiff->wall_in[l] = x[1];
+      fdiff->wall_net[l] = wnet;
+      fdiff->top_dn_dir[c] = 0.0;
+      fdiff->top_dn[c] = 1.0;
+      up = (gdn - gnet) * g.vgs + (x[1] - wnet) * g.vwg;
+      fdiff->top_net[c] = 1.0 - g.bf * roof_albedo - (gdn - gnet) * g.vgs - (x[1] - wnet) * g.vwg;
+      if (fdiff->flux_dn_layer_top) {
+        fdiff->flux_dn_layer_top[l] = open;
+        fdiff->flux_up_layer_top[l] = up;
+        fdiff->flux_dn_layer_base[l] = gdn;
+        fdiff->flux_up_layer_base[l] = gdn - gnet;
+      }
+    }
+  }
+  fdir->ground_sunlit_frac[icol] = g.vdg;
+  fdir->roof_sunlit_frac[ilay] = 1.0;
+  {
+    const or_real tan_sza = OR_SQRT(1.0 / (cos_sza * cos_sza) - 1.0);
+    fdir->wall_sunlit_frac[ilay] = 0.5 * vdw / (OR_FMAX(tan_sza, 1.0e-6) * g.npw * g.dz / (Pi * open));
+  }
+}
+
+/* simple_urban_lw (radsurf_simple_urban_lw.F90:28-257); same remark on the
+ * column index; top_emissivity / top_emission are never assigned by the
+ * reference.  interaction_matrix(2,2) uses the GROUND emissivity (:157), as the
+ * reference does. */
+static void simple_urban_lw(const ss_config *cfg, int infinite, int nlw, int icol, int ilay,
+                            const ss_canopy *cp, const ss_lw_spectral *sp, ss_flux *fint, ss_flux *fnorm) {
+  simple_geom g;
+  simple_urban_geometry(cfg, infinite, cp, ilay, 1.0, 0, &g);
+  const or_real open = 1.0 - g.bf;
+  flux_zero(fnorm, icol, ilay, 1);
+  flux_zero(fint, icol, ilay, 1);
+  for (int jb = 0; jb < nlw; ++jb) {
+    const size_t c = jb + (size_t)nlw * icol, l = jb + (size_t)nlw * ilay;
+    const or_real gem = sp->ground_emissivity[c], gemission = sp->ground_emission[c];
+    const or_real rem = sp->roof_emissivity[l], remission = sp->roof_emission[l];
+    const or_real wem = sp->wall_emissivity[l], wemission = sp->wall_emission[l];
+    or_real A[4], src[2], x[2], up;
+    E(A, 0, 0, 2) = 1.0;
+    E(A, 0, 1, 2) = -g.vwg * (1.0 - wem);
+    E(A, 1, 0, 2) = -g.vgw * (1.0 - gem);
+    E(A, 1, 1, 2) = 1.0 - g.vww * (1.0 - gem);
+    /* internal emission */
+    src[0] = g.vwg * wemission * g.npw * g.dz;
+    src[1] = g.vgw * gemission * open + g.vww * wemission * g.npw * g.dz;
+    or_solve_vec(2, A, src, x);
+    {
+      const or_real gnet = x[0] * gem - gemission * open;
+      const or_real wnet = x[1] * wem - wemission * g.npw * g.dz;
+      fint->ground_dn[c] = x[0];
+      fint->ground_net[c] = gnet;
+      fint->roof_in[l] = 0.0;
+      fint->roof_net[l] = -g.bf * remission;
+      fint->wall_in[l] = x[1];
+      fint->wall_net[l] = wnet;
+      fint->top_dn[c] = 0.0;
+      up = (x[0] - gnet) * g.vgs + (x[1] - wnet) * g.vwg;
+      fint->top_net[c] = -g.bf * remission - (x[0] - gnet) * g.vgs - (x[1] - wnet) * g.vwg;
+      if (fint->flux_dn_layer_top) {
+        fint->flux_dn_layer_top[l] = 0.0;
+        fint->flux_up_layer_top[l] = up;
+        fint->flux_dn_layer_base[l] = x[0];
+        fint->flux_up_layer_base[l] = x[0] - gnet;
+      }
+    }
+    /* incoming diffuse */
+    src[0] = g.vgs * open;
+    src[1] = g.vgw * open;
+    or_solve_vec(2, A, src, x);
+    {
+      const or_real gnet = x[0] * gem, wnet = x[1] * wem;
+      fnorm->ground_dn[c] = x[0];
+      fnorm->ground_net[c] = gnet;
+      fnorm->roof_in[l] = g.bf;
+      fnorm->roof_net[l] = g.bf * rem;
+      fnorm->wall_in[l] = x[1];
+      fnorm->wall_net[l] = wnet;
+      fnorm->top_dn[c] = 1.0;
+      up = (x[0] - gnet) * g.vgs + (x[1] - wnet) * g.vwg;
+      fnorm->top_net[c] = 1.0 - g.bf * (1.0 - rem) - (x[0] - gnet) * g.vgs - (x[1] - wnet) * g.vwg;
+      if (fnorm->flux_dn_layer_top) {
+        fnorm->flux_dn_layer_top[l] = 1.0 - g.bf;
+        fnorm->flux_up_layer_top[l] = up;
+        fnorm->flux_dn_layer_base[l] = x[0];
+        fnorm->flux_up_layer_base[l] = x[0] - gnet;
+      }
+    }
+  }
+}
+
 /* One column of radsurf (radsurf/radsurf_interface.F90:105-311); jcol 0-based */
 static int radsurf_column(const ss_config *cfg, const ss_canopy *cp, const ss_sw_spectral *sw,
                           const ss_lw_spectral *lw, ss_bc_out *bc, int jcol, ss_flux *sw_dir,
@@ -1291,11 +1517,24 @@ static int radsurf_column(const ss_config *cfg, const ss_canopy *cp, const ss_sw
     }
     break;
   }
-  default:
-    /* simple-urban tiles (types 4,5): single-layer Harman path, not part of
-     * the hot path */
+  default: {
+    /* simple-urban tiles (types 4, 5), radsurf_interface.F90:271-308 */
+    const int infinite = (irep == SS_TILE_INFINITE_STREET);
     if (nlay > 1) return SS_ERR_SIMPLE_URBAN_LAYERS;
-    return SS_ERR_TILE_NOT_ON_DEVICE;
+    if (nlay < 1) return SS_ERR_BAD_ARGUMENT;
+    if (cfg->do_sw) {
+      if (cp->cos_sza[jcol] > 0.0) {
+        simple_urban_sw(cfg, infinite, nsw, jcol, l0, cp->cos_sza[jcol], cp, sw,
+                        sw->ground_albedo + (size_t)nsw * jcol, galb_dir + (size_t)nsw * jcol,
+                        sw_dir, sw_diff);
+      } else {
+        flux_zero(sw_dir, jcol, l0, nlay);
+        flux_zero(sw_diff, jcol, l0, nlay);
+      }
+    }
+    if (cfg->do_lw) simple_urban_lw(cfg, infinite, nlw, jcol, l0, cp, lw, lw_int, lw_norm);
+    break;
+  }
   }
   return SS_OK;
 #undef C

@@ -65,6 +65,11 @@ __global__ void __launch_bounds__(256) k_night(const ss::MiscLaunch M) {
     ss::zero_unit(M.in, M.sw_diff, M.nsw, M.cols[i]);
   }
 }
+__global__ void __launch_bounds__(256) k_simple_urban(const ss::MiscLaunch M) {
+  const long u = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nmax = M.nsw > M.nlw ? M.nsw : M.nlw;
+  if (u < (long)M.ncols * nmax) ss::simple_urban_unit(M, (int)u);
+}
 __global__ void __launch_bounds__(256) k_spectrum_col(const ss::SpectrumLaunch S) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < S.ncols) ss::spectrum_col_unit(S, i);
@@ -177,6 +182,14 @@ struct HipBackend {
     hipEvent_t a = t.next(), b = t.next();
     hipEventRecord(a, stream());
     hipLaunchKernelGGL(k_night, dim3((M.ncols + 255) / 256), dim3(256), 0, stream(), M);
+    hipEventRecord(b, stream());
+    t.spans.push_back({FAM_MISC, a, b});
+  }
+  static void launch_simple_urban(const ss::MiscLaunch& M, Timers& t) {
+    const long units = (long)M.ncols * std::max(M.nsw, M.nlw);
+    hipEvent_t a = t.next(), b = t.next();
+    hipEventRecord(a, stream());
+    hipLaunchKernelGGL(k_simple_urban, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream(), M);
     hipEventRecord(b, stream());
     t.spans.push_back({FAM_MISC, a, b});
   }

@@ -123,9 +123,10 @@ class Plan {
 
   std::vector<ColumnClass> sw_classes, lw_classes;
   std::vector<int32_t> flat_cols, night_cols, lwzero_urban_cols;
+  std::vector<int32_t> simple_cols[2];   // [0] exponential model (type 4), [1] infinite street (type 5)
   std::vector<int32_t> h_indcol;
   int32_t* d_index = nullptr;
-  size_t flat_off = 0, night_off = 0;
+  size_t flat_off = 0, night_off = 0, simple_off[2] = {0, 0};
   size_t index_elems = 0;
 
   // Scratch of the layer / adding-method records, one set per "pipe": successive
@@ -334,16 +335,18 @@ class Plan {
 
   int classify() {
     sw_classes.clear(); lw_classes.clear();
-    flat_cols.clear(); night_cols.clear();
+    flat_cols.clear(); night_cols.clear(); simple_cols[0].clear(); simple_cols[1].clear();
     std::map<ClassKey, std::vector<int32_t>> swm, lwm;
     lay_first = 0; lay_count = 0;
     for (int j = istartcol - 1; j < iendcol; ++j) {
       const int irep = h_irep[j];
       if (irep == SS_TILE_FLAT) { flat_cols.push_back(j); continue; }
       if (irep == SS_TILE_SIMPLE_URBAN || irep == SS_TILE_INFINITE_STREET) {
+        // radsurf_interface.F90:271-308: one layer only; solved by the misc kernel family
         if (h_nlay[j] > 1) { error = "simple urban representations must have only one layer"; return SS_ERR_SIMPLE_URBAN_LAYERS; }
-        error = "tile types 4/5 (simple urban) are not on the device path";
-        return SS_ERR_TILE_NOT_ON_DEVICE;
+        if (h_nlay[j] < 1) { error = "canopy column without layers"; return SS_ERR_BAD_ARGUMENT; }
+        simple_cols[irep == SS_TILE_INFINITE_STREET].push_back(j);
+        continue;
       }
       if (irep < 0 || irep > 5) { error = "bad surface type"; return SS_ERR_BAD_ARGUMENT; }
       const bool urban = irep != SS_TILE_FOREST;
@@ -388,12 +391,13 @@ class Plan {
     finish(swm, sw_classes);
     finish(lwm, lw_classes);
 
-    // one device index buffer: [sw classes][lw classes][flat][night]
+    // one device index buffer: [sw classes][lw classes][flat][night][simple exp][simple inf]
     std::vector<int32_t> idx;
     for (auto& c : sw_classes) { c.dev_offset = idx.size(); idx.insert(idx.end(), c.cols.begin(), c.cols.end()); }
     for (auto& c : lw_classes) { c.dev_offset = idx.size(); idx.insert(idx.end(), c.cols.begin(), c.cols.end()); }
     flat_off = idx.size(); idx.insert(idx.end(), flat_cols.begin(), flat_cols.end());
     night_off = idx.size(); idx.insert(idx.end(), night_cols.begin(), night_cols.end());
+    for (int k = 0; k < 2; ++k) { simple_off[k] = idx.size(); idx.insert(idx.end(), simple_cols[k].begin(), simple_cols[k].end()); }
     if (idx.empty()) idx.push_back(0);
     if (!d_index || index_elems < idx.size()) {
       if (d_index) Backend::free(d_index);
@@ -589,6 +593,8 @@ class Plan {
     M.sw_diff = flux_dev("sw_norm_diff");
     M.lw_int = flux_dev("lw_internal");
     M.lw_norm = flux_dev("lw_norm");
+    M.min_building_fraction = cfg.min_building_fraction;
+    M.infinite_street = 0;
     return M;
   }
 
@@ -602,6 +608,22 @@ class Plan {
       Backend::launch_flat(make_misc(flat_off, flat_cols.size()), timers);
     }
     if (!night_cols.empty()) Backend::launch_night(make_misc(night_off, night_cols.size()), timers);
+    for (int k = 0; k < 2; ++k) {
+      if (simple_cols[k].empty()) continue;
+      auto need = [&](const char* n) {
+        if (!darr(n)) { error = std::string("required input array not provided: ") + n; return false; }
+        return true;
+      };
+      bool ok = need("canopy.dz") && need("canopy.building_fraction") && need("canopy.building_scale");
+      if (cfg.do_sw) ok = ok && need("canopy.cos_sza") && need("sw.ground_albedo") && need("sw.roof_albedo") && need("sw.wall_albedo")
+                          && (!cfg.use_sw_direct_albedo || need("sw.ground_albedo_dir"));
+      if (cfg.do_lw) ok = ok && need("lw.ground_emissivity") && need("lw.ground_emission") && need("lw.roof_emissivity")
+                          && need("lw.roof_emission") && need("lw.wall_emissivity") && need("lw.wall_emission");
+      if (!ok) return SS_ERR_BAD_ARGUMENT;
+      MiscLaunch M = make_misc(simple_off[k], simple_cols[k].size());
+      M.infinite_street = k;
+      Backend::launch_simple_urban(M, timers);
+    }
     Backend::fork(npipes);
     int nlaunched = 0;
     for (int lw = 0; lw < 2; ++lw) {

@@ -106,8 +106,8 @@ def rami5_case(scene, illumination, black_soil=False):
     return _build(nam, os.path.join(d, "scene_nc", "rami5_%s_scene.nc" % scene))
 
 
-# ---- test/single_layer (Makefile:8-20): only the SPARTACUS variant (type 2)
-# is on the hot path; types 4/5 are the simple-urban "next" row ----
+# ---- test/single_layer (Makefile:8-20): the SPARTACUS variant (type 2) and the
+# two single-layer Harman variants (types 4/5) ----
 def single_layer_case(isurfacetype=2):
     d = os.path.join(TEST, "single_layer")
     nam = inputs.change_namelist(_nam(os.path.join(d, "config.nam")), isurfacetype=isurfacetype)
@@ -134,6 +134,8 @@ def all_cases(rami5="all"):
                                    "_blacksoil" if bs else "")
                 c["rami5/" + tag] = (lambda s=scene, i=ill, b=bs: rami5_case(s, i, b))
     c["single_layer/sp"] = lambda: single_layer_case(2)
+    c["single_layer/exp"] = lambda: single_layer_case(4)
+    c["single_layer/inf"] = lambda: single_layer_case(5)
     return c
 
 
@@ -153,6 +155,23 @@ def extra_cases():
     # own longwave result for it is NaN / an emissivity of 2.7)
     for n in (3, 5, 6, 7):
         c["extra/urban-%dstream" % n] = (lambda n=n: urban_streams(n))
+
+    # test/single_layer with the three urban representations interleaved in one
+    # call and a spread of sun angles (incl. night); every column has one layer,
+    # so the reference's layer-for-column indexing in simple_urban_* is harmless
+    def single_layer_mixed():
+        import numpy as np
+        case = single_layer_case(4)
+        cp = case["canopy"]
+        cp.i_representation = np.array([(4, 5, 2)[j % 3] for j in range(cp.ncol)], dtype=np.int32)
+        cz = np.array(inputs.COS_SZA_46, dtype=np.float64)[:cp.ncol].copy()
+        cz[7] = -0.2
+        cz[8] = 0.0
+        cz[11] = 1.0
+        cp.cos_sza = cz
+        return case
+
+    c["extra/single_layer-mixed"] = single_layer_mixed
     for t in ("vis-snw-0.3-1-3", "vis-snw-0.3-2-3", "vis-snw-0.3-1-5", "vis-snw-0.3-2-6", "vis-snw-0.3-1-7"):
         c["extra/rami4pilps-" + t] = (lambda t=t: rami4pilps_case(t))
     return c

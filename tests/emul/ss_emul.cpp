@@ -38,6 +38,10 @@ struct EmulBackend {
       ss::zero_unit(M.in, M.sw_diff, M.nsw, M.cols[i]);
     }
   }
+  static void launch_simple_urban(const ss::MiscLaunch& M, Timers&) {
+    const int nmax = M.nsw > M.nlw ? M.nsw : M.nlw;
+    for (int u = 0; u < M.ncols * nmax; ++u) ss::simple_urban_unit(M, u);
+  }
   static void launch_spectrum(const ss::SpectrumLaunch& S, Timers&) {
     for (int i = 0; i < S.ncols; ++i) ss::spectrum_col_unit(S, i);
     for (int i = 0; i < S.nlays; ++i) ss::spectrum_lay_unit(S, i);

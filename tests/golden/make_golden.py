@@ -5,6 +5,7 @@ compiled reference in oracle/_ref):
 
     python tests/golden/make_golden.py            # the reference's own test runs
     python tests/golden/make_golden.py --extra    # + stream counts its tests never select (tests/cases.py)
+    python tests/golden/make_golden.py [--extra] --only=SUBSTRING   # just the cases whose name matches
 
 For every run of the reference's own `make test` that exercises the hot path
 (tests/cases.py) this freezes the solver inputs and the reference's fp64
@@ -28,7 +29,10 @@ def main():
     checker.build()
     total = 0
     todo = cases.extra_cases() if "--extra" in sys.argv else cases.all_cases(rami5="subset")
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
     for name, build in todo.items():
+        if only and not any(o in name for o in only):
+            continue
         case = build()
         outputs, _ = checker.run_ref(case["config"], case["canopy"], case["sw"], case["lw"],
                                      want_profiles=True,

@@ -19,7 +19,8 @@ from tests.test_hip_parity import REFERENCE_SINGULAR
 # one case per code path, kept small so the CPU suite stays within minutes
 CASES = ["simple__test_surfaces", "simple__test_surfaces_1stream", "simple__test_empty_layers",
          "simple__test_nearly_empty_layers", "simple__test_overhang", "simple__test_noscat",
-         "simple__test_closed", "single_layer__sp", "urban__1stream", "urban__2stream",
+         "simple__test_closed", "single_layer__sp", "single_layer__exp", "single_layer__inf",
+         "extra__single_layer-mixed", "urban__1stream", "urban__2stream",
          "urban__4stream", "urban__single", "rami4pilps__vis-med-0.3", "rami4pilps__vis-snw-0.3-2-4",
          "rami5__HET07_JPS_SUM-56-direct",
          # stream counts beyond the reference's own tests (tests/cases.py: extra_cases)
