@@ -231,6 +231,45 @@ def c4_mixed(ncol=1_000_000, seed=12345, nsw=14, nlw=16):
                    top_flux_dn_lw=np.full((ncol, nlw), StefanBoltzmann * t_sky ** 4 / nlw))
 
 
+def ragged_all_tiles(ncol=96, seed=2024, nsw=2, nlw=3, simple_urban=True):
+    """Edge-case workload (not a BASELINE config): every tile type of radsurf in
+    one call - flat (no layers), forest, urban, vegetated urban, simple urban and
+    infinite street (one layer each) - with a different number of layers per
+    column (1..10), several bands, and a few night-time columns.  Built from the
+    C4 columns by keeping only the lowest nlay layers of each.
+    simple_urban=False leaves types 4/5 out: next to multi-layer columns the
+    reference's simple_urban_* index other columns' results,
+    so only that variant can be pinned to the compiled reference."""
+    from .types import (ITileFlat, ITileUrban, ITileSimpleUrban, ITileInfiniteStreet)
+    from . import abi
+    case = c4_mixed(ncol, seed, nsw, nlw)
+    cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
+    rng = np.random.default_rng(seed + 1)
+    L = 10
+    types = np.array([ITileFlat, ITileForest, ITileUrban, ITileVegetatedUrban, ITileSimpleUrban,
+                      ITileInfiniteStreet, ITileVegetatedUrban, ITileForest], dtype=np.int32)
+    if not simple_urban:
+        types = types[(types != ITileSimpleUrban) & (types != ITileInfiniteStreet)]
+    irep = types[np.arange(ncol) % types.size]
+    nlay = rng.integers(1, L + 1, size=ncol).astype(np.int32)
+    nlay[irep == ITileFlat] = 0
+    nlay[(irep == ITileSimpleUrban) | (irep == ITileInfiniteStreet)] = 1
+    keep = (np.arange(L)[None, :] < nlay[:, None]).reshape(-1)       # packed (column, layer) order
+    ntot_rect = ncol * L
+    for obj, names in ((cp, abi.CANOPY_REAL_FIELDS), (sw, abi.SW_FIELDS), (lw, abi.LW_FIELDS)):
+        for n in names:
+            a = getattr(obj, n)
+            if a is not None and a.shape[0] == ntot_rect:
+                setattr(obj, n, np.ascontiguousarray(a[keep]))
+    cp.set_layers(nlay)
+    cp.i_representation = irep
+    cz = rng.uniform(0.05, 1.0, size=ncol)
+    cz[5::11] = -0.3            # night
+    cz[7::13] = 0.0
+    cp.cos_sza = cz
+    return _finish(cfg, cp, sw, lw)
+
+
 # Algorithmic HBM bytes per column (SURVEY.md section 8d): fp64 inputs the solver
 # reads + outputs it writes, no flux profiles.
 def algorithmic_bytes_per_column(case):

@@ -172,6 +172,17 @@ def extra_cases():
         return case
 
     c["extra/single_layer-mixed"] = single_layer_mixed
+
+    # synthetic: flat, forest, urban and vegetated-urban tiles with 1..10 layers per
+    # column in one call, 2 SW + 3 LW bands, day and night (workloads.ragged_all_tiles)
+    def ragged():
+        from spartacus_surface_amd import workloads
+        case = workloads.ragged_all_tiles(simple_urban=False)
+        case.setdefault("driver", None)
+        case["do_simple_spectrum"] = False
+        return case
+
+    c["extra/ragged-tiles"] = ragged
     for t in ("vis-snw-0.3-1-3", "vis-snw-0.3-2-3", "vis-snw-0.3-1-5", "vis-snw-0.3-2-6", "vis-snw-0.3-1-7"):
         c["extra/rami4pilps-" + t] = (lambda t=t: rami4pilps_case(t))
     return c

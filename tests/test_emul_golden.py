@@ -20,7 +20,7 @@ from tests.test_hip_parity import REFERENCE_SINGULAR
 CASES = ["simple__test_surfaces", "simple__test_surfaces_1stream", "simple__test_empty_layers",
          "simple__test_nearly_empty_layers", "simple__test_overhang", "simple__test_noscat",
          "simple__test_closed", "single_layer__sp", "single_layer__exp", "single_layer__inf",
-         "extra__single_layer-mixed", "urban__1stream", "urban__2stream",
+         "extra__single_layer-mixed", "extra__ragged-tiles", "urban__1stream", "urban__2stream",
          "urban__4stream", "urban__single", "rami4pilps__vis-med-0.3", "rami4pilps__vis-snw-0.3-2-4",
          "rami5__HET07_JPS_SUM-56-direct",
          # stream counts beyond the reference's own tests (tests/cases.py: extra_cases)
@@ -56,3 +56,20 @@ def test_emulated_kernels_vs_golden(emul, path):
         noise = {k: bar / fixture_io.NOISE_FACTOR for k in noise}
     bad = fixture_io.parity_violations(got, expected, noise)
     assert not bad, "outside the parity bar: %s" % bad[:5]
+
+
+def test_emulated_ragged_all_tile_types_vs_oracle(emul):
+    """All six tile types incl. the single-layer urban ones next to multi-layer
+    columns (where the compiled reference cannot serve as the checker, DESIGN.md
+    section 7): emulated device code against the CPU restatement."""
+    from oracle import checker
+    from spartacus_surface_amd import workloads
+    case = workloads.ragged_all_tiles(ncol=96, seed=2024)
+    a = (case["config"], case["canopy"], case["sw"], case["lw"])
+    out, nfail = emul.run_emul(*a, want_profiles=True)
+    assert nfail == 0
+    ref = fixture_io.flatten_outputs(checker.run_oracle(*a, want_profiles=True)[0])
+    truth = fixture_io.flatten_outputs(checker.run_oracle(*a, want_profiles=True, quad=True)[0])
+    bad = fixture_io.parity_violations(fixture_io.flatten_outputs(out), ref,
+                                       fixture_io.rel_errors(ref, truth))
+    assert not bad, bad[:5]

@@ -209,6 +209,29 @@ def test_synthetic_c4_mixed_multiband_vs_oracle():
     assert not bad, bad[:5]
 
 
+def test_ragged_all_tile_types_vs_oracle():
+    """Every tile type (flat, forest, urban, vegetated urban, simple urban, infinite
+    street) with 1..10 layers per column, several bands, day and night, in one call."""
+    from spartacus_surface_amd import workloads
+    case = workloads.ragged_all_tiles(ncol=640, seed=99)
+    case["want_profiles"] = True
+    _, bad = _check_against_oracle(case, 640)
+    assert not bad, bad[:5]
+
+
+def test_empty_column_range_is_a_no_op():
+    """iendcol < istartcol: nothing is read or written (the reference's loop runs zero times)."""
+    radsurf = _hip()
+    path = [p for p in golden_files() if p.endswith("simple__test_surfaces.npz")][0]
+    case, _ = fixture_io.load_case(path)
+    out = _alloc(case)
+    flat0 = {k: np.array(v, copy=True) for k, v in fixture_io.flatten_outputs(out).items()}
+    radsurf.radsurf(case["config"], case["canopy"], case["sw"], case["lw"], out["bc_out"], 3, 2,
+                    out["sw_norm_dir"], out["sw_norm_diff"], out["lw_internal"], out["lw_norm"])
+    for k, v in fixture_io.flatten_outputs(out).items():
+        assert np.array_equal(v, flat0[k]), k
+
+
 def test_full_size_properties_c3():
     """Size-independent properties at the full bench size (1e6 columns x 10
     layers): (i) columns are independent, so the first 2048 columns of the big
