@@ -18,8 +18,13 @@
 #pragma once
 
 #include "ss_common.hpp"
+#include "ss_linalg_blocked.hpp"
 
 namespace ss {
+
+// orders above SS_UNROLL_MAX go to the register-tiled routines of ss_linalg_blocked.hpp
+template <int A, int B = 0, int C = 0>
+constexpr bool kBigOrder = (A > SS_UNROLL_MAX) || (B > SS_UNROLL_MAX) || (C > SS_UNROLL_MAX);
 
 template <int N>
 SS_HD void vec_zero(double* x) {
@@ -61,6 +66,10 @@ SS_HD void mat_copy(const double* A, double* B) {
 // C(M x N) = A(M x K) * B(K x N)   (mat_x_mat :248, rect_mat_x_mat :335)
 template <int M, int K, int N>
 SS_HD void mat_mul(const double* A, const double* B, double* C) {
+  if constexpr (kBigOrder<M, K, N>) {
+    blk::mat_mul<M, K, N, false, false>(A, nullptr, B, C);
+    return;
+  }
   SS_UNROLL_N(N)
   for (int j = 0; j < N; ++j) {
     SS_UNROLL_N(M)
@@ -76,6 +85,10 @@ SS_HD void mat_mul(const double* A, const double* B, double* C) {
 // C += A*B
 template <int M, int K, int N>
 SS_HD void mat_mul_acc(const double* A, const double* B, double* C) {
+  if constexpr (kBigOrder<M, K, N>) {
+    blk::mat_mul<M, K, N, true, false>(A, nullptr, B, C);
+    return;
+  }
   SS_UNROLL_N(N)
   for (int j = 0; j < N; ++j) {
     SS_UNROLL_N(M)
@@ -91,6 +104,10 @@ SS_HD void mat_mul_acc(const double* A, const double* B, double* C) {
 // C (+)= A diag(e) B without forming A diag(e) or diag(e) B
 template <int M, int K, int N, bool ACC>
 SS_HD void mat_mul_rs(const double* A, const double* e, const double* B, double* C) {
+  if constexpr (kBigOrder<M, K, N>) {
+    blk::mat_mul<M, K, N, ACC, true>(A, e, B, C);
+    return;
+  }
   SS_UNROLL_N(N)
   for (int j = 0; j < N; ++j) {
     double eb[K];
@@ -148,6 +165,10 @@ SS_HD void lu_factor(double* A) {
     A[3] = inv_det * a;
     return;
   }
+  if constexpr (kBigOrder<N>) {
+    blk::lu_factor<N>(A);
+    return;
+  }
   SS_UNROLL_N(N)
   for (int j2 = 0; j2 < N; ++j2) {
     SS_UNROLL_N(N)
@@ -199,6 +220,10 @@ SS_HD void lu_solve(const double* LU, double* x) {
 // Solve A X = B in place, B is N x M  (solve_mat :1175, solve_rect_mat :1119)
 template <int N, int M>
 SS_HD void lu_solve_mat(const double* LU, double* B) {
+  if constexpr (kBigOrder<N> && M >= 2) {
+    blk::lu_solve_mat<N, M>(LU, B);
+    return;
+  }
   SS_UNROLL_N(M)
   for (int j = 0; j < M; ++j) lu_solve<N>(LU, B + j * N);
 }
@@ -209,6 +234,12 @@ SS_HD void lu_invert(const double* LU, double* X) {
   if (N <= 2) {
     SS_UNROLL_FULL
     for (int k = 0; k < N * N; ++k) X[k] = LU[k];
+    return;
+  }
+  if constexpr (kBigOrder<N>) {
+    for (int k = 0; k < N * N; ++k) X[k] = 0.0;
+    for (int k = 0; k < N; ++k) X[k + k * N] = 1.0;
+    blk::lu_solve_mat<N, N>(LU, X);
     return;
   }
   SS_UNROLL_N(N)

@@ -636,7 +636,12 @@ class Plan {
         for (size_t first = 0; first < c.cols.size(); first += chunk) {
           const size_t count = std::min(chunk, c.cols.size() - first);
           const int chunk_maxlay = h_nlay[c.cols[first]];   // sorted descending
-          const int pipe = nlaunched++ % npipes;
+          // Orders above SS_UNROLL_MAX keep their matrices in the hardware scratch
+          // (tens of KB per lane, GBs per queue): concurrent queues then fight over
+          // it (measured 5.5e5 -> 3.2e5 columns/s with four streams at n = 12), so
+          // those classes stay on the first stream.
+          const bool big_order = c.key.nreg * c.key.ns > SS_UNROLL_MAX;
+          const int pipe = big_order ? 0 : nlaunched++ % npipes;
           Launch L = make_launch(c, lw != 0, first, count, chunk_maxlay, pipe);
           Backend::launch_solver(c.key, lw != 0, L, timers, pipe);
         }
