@@ -196,6 +196,22 @@ SS_HD double lw_partner_value(double v, int pass, double* slot) {
 // source switched off and a unit incoming flux, so both run one instruction
 // stream and share their memory requests; software-pipelined like the
 // shortwave sweep (ss_column_sw.hpp).
+// Staging priority of the per-layer outputs of the downward kernel (see PUTL there)
+constexpr int lw_down_slot(int F) {
+  switch (F) {
+    case F_CLEAR_AIR_ABS: return 0;
+    case F_VEG_ABS: return 1;
+    case F_VEG_AIR_ABS: return 2;
+    case F_WALL_IN: return 3;
+    case F_WALL_NET: return 4;
+    case F_ROOF_IN: return 5;
+    case F_ROOF_NET: return 6;
+    default: return -1;
+  }
+}
+constexpr int kLwDownSlotField[7] = {F_CLEAR_AIR_ABS, F_VEG_ABS, F_VEG_AIR_ABS, F_WALL_IN, F_WALL_NET,
+                                     F_ROOF_IN, F_ROOF_NET};
+
 template <bool URBAN, int NREG, int NS>
 SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
   constexpr int N = NREG * NS;
@@ -218,7 +234,11 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
 
 #define FSEL(F) (internal ? L.flux_a.f[F] : L.flux_b.f[F])
 #define PUTC(F, v) do { double* p_ = FSEL(F); if (p_) p_[cidx] = (v); } while (0)
-#define PUTL(F, v) do { double* p_ = FSEL(F); if (p_) p_[sidx] = (v); } while (0)
+  // per-layer outputs staged in LDS and written out after the sweep (see ss_column_sw.hpp)
+  LaneLds obuf;
+  const int nbuf = kLaneLdsSlots / (L.maxlay > 0 ? L.maxlay : 1);
+#define PUTL(F, v) do { double* p_ = FSEL(F); if (p_) { constexpr int s_ = lw_down_slot(F); \
+    if (s_ >= 0 && s_ < nbuf) obuf.put(s_ * L.maxlay + jlay, (v)); else p_[sidx] = (v); } } while (0)
 
   double dn_above[N], up_above[N];
   vec_zero<N>(dn_above);
@@ -423,6 +443,15 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
         if (L.flux_a.f[F_GROUND_VERTICAL_DIFF]) L.flux_a.f[F_GROUND_VERTICAL_DIFF][cidx] = gvd2;
         if (L.flux_b.f[F_GROUND_VERTICAL_DIFF]) L.flux_b.f[F_GROUND_VERTICAL_DIFF][cidx] = 0.0;
       }
+    }
+  }
+  // the staged per-layer fields, all layers of a field back to back
+  SS_UNROLL_FULL
+  for (int s_ = 0; s_ < 7; ++s_) {
+    double* p_ = FSEL(kLwDownSlotField[s_]);
+    if (s_ < nbuf && p_) {
+      for (int jlay = 0; jlay < nlay; ++jlay)
+        p_[(long)jb + (long)nspec * (l0 + jlay)] = obuf.get(s_ * L.maxlay + jlay);
     }
   }
 #undef PUTC

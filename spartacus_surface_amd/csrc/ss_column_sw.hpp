@@ -240,6 +240,25 @@ struct SwDownIn {
   }
 };
 
+// Staging priority of the per-layer outputs of the downward kernel (see PUTL there)
+constexpr int sw_down_slot(int F) {
+  switch (F) {
+    case F_CLEAR_AIR_ABS: return 0;
+    case F_VEG_ABS: return 1;
+    case F_VEG_AIR_ABS: return 2;
+    case F_VEG_ABS_DIR: return 3;
+    case F_WALL_IN: return 4;
+    case F_WALL_NET: return 5;
+    case F_ROOF_IN: return 6;
+    case F_ROOF_NET: return 7;
+    case F_WALL_IN_DIR: return 8;
+    case F_ROOF_IN_DIR: return 9;
+    default: return -1;
+  }
+}
+constexpr int kSwDownSlotField[10] = {F_CLEAR_AIR_ABS, F_VEG_ABS, F_VEG_AIR_ABS, F_VEG_ABS_DIR, F_WALL_IN,
+                                      F_WALL_NET, F_ROOF_IN, F_ROOF_NET, F_WALL_IN_DIR, F_ROOF_IN_DIR};
+
 // ---- section 5: the downward flux passes (k_down) ----
 // One lane = (column, band, pass): pass 0 is normalised by the direct flux at
 // canopy top (sw_norm_dir, forest :530-676 / urban :676-874), pass 1 by the
@@ -271,7 +290,16 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
   // (both pointers are wave-uniform scalars; the select is one v_cndmask pair)
 #define FSEL(F) (dirpass ? L.flux_a.f[F] : L.flux_b.f[F])
 #define PUTC(F, v) do { double* p_ = FSEL(F); if (p_) p_[cidx] = (v); } while (0)
-#define PUTL(F, v) do { double* p_ = FSEL(F); if (p_) p_[sidx] = (v); } while (0)
+// Per-layer outputs: a lane writes one 8-byte element of a field per layer, ~20 us
+  // apart, into lines it shares with nobody until the column is finished; at
+  // 66 KB of such lines per wave L2 evicts them half-written (measured: the
+  // stores are 2.2 of the 7.1 ms of this kernel, three times their bytes' worth).
+  // The fields that fit are therefore staged in LDS and written out back to back
+  // after the sweep, so that every line is completed while it is still in L2.
+  LaneLds obuf;
+  const int nbuf = kLaneLdsSlots / (L.maxlay > 0 ? L.maxlay : 1);   // fields that fit
+#define PUTL(F, v) do { double* p_ = FSEL(F); if (p_) { constexpr int s_ = sw_down_slot(F); \
+    if (s_ >= 0 && s_ < nbuf) obuf.put(s_ * L.maxlay + jlay, (v)); else p_[sidx] = (v); } } while (0)
 
   double dir_above[D], diff_above[N], up_above[N];
   dir_above[0] = dirpass ? 1.0 / cos_sza : 0.0;
@@ -557,6 +585,15 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
     PUTC(F_GROUND_VERTICAL_DIFF, gvd);
     if (jb == itransp && FSEL(F_GROUND_SUNLIT_FRAC))
       FSEL(F_GROUND_SUNLIT_FRAC)[col] = dirpass ? gdd / (cos_sza * flux_dn_dir_clear) : 0.0;
+  }
+  // the staged per-layer fields, all layers of a field back to back
+  SS_UNROLL_FULL
+  for (int s_ = 0; s_ < 10; ++s_) {
+    double* p_ = FSEL(kSwDownSlotField[s_]);
+    if (s_ < nbuf && p_) {
+      for (int jlay = 0; jlay < nlay; ++jlay)
+        p_[(long)jb + (long)nspec * (l0 + jlay)] = obuf.get(s_ * L.maxlay + jlay);
+    }
   }
 #undef PUTC
 #undef PUTL

@@ -51,6 +51,28 @@
 
 namespace ss {
 
+// Per-lane staging space in LDS for the downward kernels: kLaneLdsSlots doubles
+// per lane, lane-interleaved (a wave's access to one slot is one conflict-free
+// 512-byte row).  Their blocks are one wave (kBlock = 64) and they run one wave
+// per SIMD, so four blocks share the 160 KB of a CU: 40 KB = 80 doubles per lane.
+// Host builds (the emulator of tests/emul) use a plain array.
+constexpr int kLaneLdsSlots = 80;
+struct LaneLds {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double* p;
+  SS_HD LaneLds() {
+    __shared__ double lds[kLaneLdsSlots * 64];
+    p = lds + threadIdx.x;
+  }
+  SS_HD void put(int slot, double v) const { p[slot * 64] = v; }
+  SS_HD double get(int slot) const { return p[slot * 64]; }
+#else
+  double a[kLaneLdsSlots];
+  SS_HD void put(int slot, double v) { a[slot] = v; }
+  SS_HD double get(int slot) const { return a[slot]; }
+#endif
+};
+
 constexpr double kPi = 3.14159265358979323846;   // radtool/radiation_constants.F90:24
 constexpr double kStefanBoltzmann = 5.67037321e-8;  // radiation_constants.F90:26
 constexpr int kDevMaxStreams = 8;                // instantiated stream counts: 1,2,4,8

@@ -33,10 +33,22 @@ namespace {
 
 template <bool U, int R, int NS, bool LW>
 __global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_LAYER)) k_layer(const Launch L) {
-  const int cu = blockIdx.x * kBlock + threadIdx.x;
+#ifndef SS_LAYER_GRID_2D
+  // Block -> (tile of 64 column units, layer).  The per-layer inputs of a column
+  // sit 8 * nlay bytes apart, so one block uses 8 bytes of every 128-byte line it
+  // fetches; the other layers of the same tile use the rest.  Workgroups go to the
+  // 8 XCDs round-robin and every XCD has its own L2, so the blocks of one tile get
+  // ids that are equal modulo 8 and close together: same L2, same time.
+  const int per_group = 8 * L.maxlay;
+  const int group = blockIdx.x / per_group, r = blockIdx.x % per_group;
+  const int tile = group * 8 + (r & 7), jlay = r >> 3;
+#else
+  const int tile = blockIdx.x, jlay = blockIdx.y;
+#endif
+  const int cu = tile * kBlock + threadIdx.x;
   if (cu >= L.ncu) return;
-  if (LW) layer_unit_lw<U, R, NS>(L, cu, (int)blockIdx.y);
-  else layer_unit_sw<U, R, NS>(L, cu, (int)blockIdx.y);
+  if (LW) layer_unit_lw<U, R, NS>(L, cu, jlay);
+  else layer_unit_sw<U, R, NS>(L, cu, jlay);
 }
 
 // upward sweep (adding method)
@@ -73,8 +85,13 @@ void launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev) {
   }
   const unsigned gx = (unsigned)((L.ncu + kBlock - 1) / kBlock);
   if (ev) hipEventRecord(ev[0], stream);
-  hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx, (unsigned)L.maxlay),
-                     dim3(kBlock), 0, stream, L);
+#ifndef SS_LAYER_GRID_2D
+  const dim3 glayer(((gx + 7) / 8) * 8 * (unsigned)L.maxlay);
+#else
+  const dim3 glayer(gx, (unsigned)L.maxlay);
+#endif
+  hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), glayer, dim3(kBlock), 0,
+                     stream, L);
   if (ev) hipEventRecord(ev[1], stream);
   hipLaunchKernelGGL((k_column<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx), dim3(kBlock), 0,
                      stream, L);

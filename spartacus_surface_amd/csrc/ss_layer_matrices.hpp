@@ -85,12 +85,45 @@ SS_HD long rec_base(int jlay, int maxlay, int nelem, int cu) {
   return ((tile * maxlay + jlay) * nelem) * kRecStride + 2 * lane;
 }
 
+// Records are written once by one kernel and read once by a later one, GBs
+// later: they move with the non-temporal hint, so that they do not displace what
+// L2 is useful for here - per-layer inputs shared by neighbouring blocks and flux
+// outputs still being merged into full lines (C3: 31.0 -> 32.2e6 columns/s;
+// -DSS_NO_NT switches the hint off).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef double ss_double2 __attribute__((ext_vector_type(2)));
+#endif
+SS_HD RecPair rec_pair_load(const double* p) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SS_NO_NT)
+  const ss_double2 t = __builtin_nontemporal_load(reinterpret_cast<const ss_double2*>(p));
+  RecPair v;
+  v.x = t.x;
+  v.y = t.y;
+  return v;
+#else
+  return *reinterpret_cast<const RecPair*>(p);
+#endif
+}
+SS_HD void rec_pair_store(double* p, double v0, double v1) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SS_NO_NT)
+  ss_double2 t;
+  t.x = v0;
+  t.y = v1;
+  __builtin_nontemporal_store(t, reinterpret_cast<ss_double2*>(p));
+#else
+  RecPair v;
+  v.x = v0;
+  v.y = v1;
+  *reinterpret_cast<RecPair*>(p) = v;
+#endif
+}
+
 // NEL consecutive elements starting at the EVEN element "off" of a record
 template <int NEL>
 SS_HD void rec_load(const double* rec, long stride, int off, double* dst) {
   SS_UNROLL_FULL
   for (int k = 0; k < NEL; k += 2) {
-    const RecPair v = *reinterpret_cast<const RecPair*>(rec + (long)(off + k) * stride);
+    const RecPair v = rec_pair_load(rec + (long)(off + k) * stride);
     dst[k] = v.x;
     if (k + 1 < NEL) dst[k + 1] = v.y;
   }
@@ -99,10 +132,7 @@ template <int NEL>
 SS_HD void rec_store(double* rec, long stride, int off, const double* src) {
   SS_UNROLL_FULL
   for (int k = 0; k < NEL; k += 2) {
-    RecPair v;
-    v.x = src[k];
-    v.y = (k + 1 < NEL) ? src[k + 1] : 0.0;
-    *reinterpret_cast<RecPair*>(rec + (long)(off + k) * stride) = v;
+    rec_pair_store(rec + (long)(off + k) * stride, src[k], (k + 1 < NEL) ? src[k + 1] : 0.0);
   }
 }
 
@@ -113,10 +143,7 @@ struct RecWriter {
   unsigned long long* stamps;   // profiling builds (SS_STAMPS): section counters, else unused
   // elements e (even) and e+1
   SS_HD void put2(int e, double v0, double v1) const {
-    RecPair v;
-    v.x = v0;
-    v.y = v1;
-    *reinterpret_cast<RecPair*>(rec + (long)e * stride) = v;
+    rec_pair_store(rec + (long)e * stride, v0, v1);
   }
 };
 
