@@ -288,7 +288,7 @@ int ss_plan_scale_and_sum(ss_plan *plan, const double *top_flux_dn_sw,
 int ss_plan_download_sums(ss_plan *plan, ss_flux *sw_flux, ss_flux *lw_flux);
 /* Number of concurrent HIP streams ("pipes") the next ss_plan_solve spreads its
  * chunk launches over: 1 = strictly serial kernels (what per-kernel profiling
- * wants), up to 4 (default 4, env SPARTACUS_PIPES) = the memory-bound column
+ * wants), up to 8 (default 4 - more did not pay on MI355X -, env SPARTACUS_PIPES) = the memory-bound column
  * kernels of one chunk overlap with the arithmetic-bound layer kernels of others.  No
  * counterpart in the reference (its concurrency is the OpenMP block loop,
  * driver/spartacus_surface_driver.F90:206-233). */

@@ -43,7 +43,7 @@ hipStream_t stream() {
 
 // Worker streams of the solve ("pipes" of ss_plan_impl.hpp): pipe 0 is the
 // library's main stream, further pipes fork from it and join it again.
-constexpr int kMaxPipes = 4;
+constexpr int kMaxPipes = 8;
 hipStream_t g_pipe[kMaxPipes] = {};
 hipEvent_t g_fork_ev = nullptr, g_join_ev[kMaxPipes] = {};
 

@@ -235,8 +235,8 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
 #define FSEL(F) (internal ? L.flux_a.f[F] : L.flux_b.f[F])
 #define PUTC(F, v) do { double* p_ = FSEL(F); if (p_) p_[cidx] = (v); } while (0)
   // per-layer outputs staged in LDS and written out after the sweep (see ss_column_sw.hpp)
-  LaneLds obuf;
-  const int nbuf = kLaneLdsSlots / (L.maxlay > 0 ? L.maxlay : 1);
+  LaneLds<(N <= SS_UNROLL_MAX)> obuf;
+  const int nbuf = obuf.kSlots / (L.maxlay > 0 ? L.maxlay : 1);
 #define PUTL(F, v) do { double* p_ = FSEL(F); if (p_) { constexpr int s_ = lw_down_slot(F); \
     if (s_ >= 0 && s_ < nbuf) obuf.put(s_ * L.maxlay + jlay, (v)); else p_[sidx] = (v); } } while (0)
 

@@ -296,8 +296,8 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
   // stores are 2.2 of the 7.1 ms of this kernel, three times their bytes' worth).
   // The fields that fit are therefore staged in LDS and written out back to back
   // after the sweep, so that every line is completed while it is still in L2.
-  LaneLds obuf;
-  const int nbuf = kLaneLdsSlots / (L.maxlay > 0 ? L.maxlay : 1);   // fields that fit
+  LaneLds<(N <= SS_UNROLL_MAX)> obuf;
+  const int nbuf = obuf.kSlots / (L.maxlay > 0 ? L.maxlay : 1);   // fields that fit
 #define PUTL(F, v) do { double* p_ = FSEL(F); if (p_) { constexpr int s_ = sw_down_slot(F); \
     if (s_ >= 0 && s_ < nbuf) obuf.put(s_ * L.maxlay + jlay, (v)); else p_[sidx] = (v); } } while (0)
 

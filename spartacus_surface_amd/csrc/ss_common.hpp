@@ -57,7 +57,9 @@ namespace ss {
 // per SIMD, so four blocks share the 160 KB of a CU: 40 KB = 80 doubles per lane.
 // Host builds (the emulator of tests/emul) use a plain array.
 constexpr int kLaneLdsSlots = 80;
+template <bool ON>
 struct LaneLds {
+  static constexpr int kSlots = kLaneLdsSlots;
 #if defined(__HIP_DEVICE_COMPILE__)
   double* p;
   SS_HD LaneLds() {
@@ -71,6 +73,13 @@ struct LaneLds {
   SS_HD void put(int slot, double v) { a[slot] = v; }
   SS_HD double get(int slot) const { return a[slot]; }
 #endif
+};
+// Orders above SS_UNROLL_MAX run four waves per SIMD: no LDS to spare, nothing staged
+template <>
+struct LaneLds<false> {
+  static constexpr int kSlots = 0;
+  SS_HD void put(int, double) const {}
+  SS_HD double get(int) const { return 0.0; }
 };
 
 constexpr double kPi = 3.14159265358979323846;   // radtool/radiation_constants.F90:24

@@ -133,7 +133,7 @@ class Plan {
   // chunks (and the SW and LW families) alternate between the pipes, which the
   // backend maps to concurrent streams, so that the memory-bound column kernels
   // of one chunk overlap with the arithmetic-bound layer kernel of the next.
-  static constexpr int kMaxPipes = 4;
+  static constexpr int kMaxPipes = 8;
   int npipes = 1;
   double* d_lay[kMaxPipes] = {};
   double* d_col[kMaxPipes] = {};
