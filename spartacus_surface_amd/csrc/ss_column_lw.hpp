@@ -15,11 +15,9 @@ namespace ss {
 
 template <int N>
 struct LwColRec {
-  static constexpr int AAB = 0;                       // a_above(l)        N x N
-  static constexpr int PDN = AAB + rec_even(N * N);   // P = Den^-1 T      N x N   (Den = I - a_above R)
+  static constexpr int PDN = 0;                       // P = Den^-1 T      N x N   (Den = I - a_above R)
   static constexpr int ABE = PDN + rec_even(N * N);   // a_below(l+1)      N x N (canopy part)
-  static constexpr int SAB = ABE + rec_even(N * N);   // source_above(l)   N
-  static constexpr int SBE = SAB + rec_even(N);       // source_below(l+1) N (canopy part)
+  static constexpr int SBE = ABE + rec_even(N * N);   // source_below(l+1) N (canopy part)
   static constexpr int RSD = SBE + rec_even(N);       // Den^-1 (R source_above + source_lay)  N
   static constexpr int NELEM = RSD + rec_even(N);
   // flux at the layer base in the downward sweep = P flux_top + RSD (forest :547-553)
@@ -104,8 +102,6 @@ SS_HD void column_up_lw(const Launch& L, int cu) {
       rec_load<N * N>(lrec, stride, LRec::R, R);
       rec_load<N * N>(lrec, stride, LRec::T, T);
       rec_load<N>(lrec, stride, LRec::SRC, Sl);
-      rec_store<N * N>(crec, stride, CRec::AAB, Aab);
-      rec_store<N>(crec, stride, CRec::SAB, Sab);
       lw_adding_step<N>(Aab, Sab, R, T, Sl, Den, Abe, Sbe);
       rec_store<N * N>(crec, stride, CRec::ABE, Abe);
       rec_store<N>(crec, stride, CRec::SBE, Sbe);
@@ -255,16 +251,50 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
   for (int js = 0; js < NS; ++js) emiss_factor += lg.hweight[js] / lg.mu[js];
   emiss_factor = 2.0 * emiss_factor;
 
-  // group 1 of the top layer and its scalars; fractions of the layer above
+  // Crossing the interface at the top of layer jl (see ss_column_sw.hpp): downward
+  // flux through V, upward flux just below it from a_below / source_below of layer
+  // jl and its exposed roofs, upward flux just above it through U - which is the
+  // reference's a_above flux + source_above at the base of the layer above, with
+  // a_above = (U x I) [a_below (V x I); roof rows] applied to the vector instead of
+  // being stored as a matrix by the upward sweep.
+  auto cross = [&](const LwLayerIn<URBAN, NREG>& dlo, bool upper_is_sky, double vf_up, double bf_up,
+                   const double* ABE, const double* SBE, const double* dn_ab, double* dn_below,
+                   double* up_below, double* up_ab) {
+    double U[NREG * DB], V[DB * NREG];
+    interface_overlap_vals<URBAN, true, NREG>(L.cfg.min_vegetation_fraction, upper_is_sky, vf_up, bf_up,
+                                              false, dlo.g.veg_fraction, dlo.g.building_fraction, U, V);
+    apply_V_vec<NREG, DB, NS>(V, dn_ab, dn_below);
+    mat_vec<N, N>(ABE, dn_below, up_below);
+    SS_UNROLL_N(N)
+    for (int i = 0; i < N; ++i) up_below[i] = up_below[i] + src * SBE[i];
+    if (URBAN) {
+      const double roof_a = 1.0 - dlo.roof_emissivity;
+      double exposed_roof_frac;
+      if (!upper_is_sky) exposed_roof_frac = ss_max(0.0, dlo.g.building_fraction - bf_up);
+      else exposed_roof_frac = dlo.g.building_fraction;
+      SS_UNROLL_FULL
+      for (int s = 0; s < NS; ++s) {
+        double acc = 0.0;
+        SS_UNROLL_FULL
+        for (int s2 = 0; s2 < NS; ++s2) acc += (roof_a * lg.hweight[s]) * dn_below[N + s2];
+        up_below[N + s] = acc + src * (lg.hweight[s] * dlo.roof_emission * exposed_roof_frac);
+      }
+    }
+    if (up_ab) apply_U_mat<NREG, DB, NS, 1>(U, up_below, up_below + N, up_ab);
+  };
+
+  // top layer: its scalars and group 1 (a_below, source_below), then the interface to the free atmosphere
   LwLayerIn<URBAN, NREG> din;
-  double ABE[N * N], SBE[N];
-  double vf_up = 0.0, bf_up = 0.0;
+  double dn_below[NB], up_below[NB];
   if (nlay > 0) {
     const int jlay = nlay - 1;
     const double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
+    double ABE[N * N], SBE[N];
     din.load(in, l0 + jlay, (long)jb + (long)nspec * (l0 + jlay));
     rec_load<N * N>(crec, st, CRec::ABE, ABE);
     rec_load<N>(crec, st, CRec::SBE, SBE);
+    SS_LOAD_FENCE();
+    cross(din, true, 0.0, 0.0, ABE, SBE, dn_above, dn_below, up_below, nullptr);
   }
 
   for (int jlay = nlay - 1; jlay >= 0; --jlay) {
@@ -274,37 +304,16 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
     const long sidx = (long)jb + (long)nspec * lay;
     const LwLayerIn<URBAN, NREG> dcur = din;
 
-    // ---- issue group 2 (P, RSD), work on group 1 ----
+    // ---- issue group 2 (P, RSD), work on the fluxes just below the top interface ----
     double P[N * N], RSD[N];
     rec_load<N * N>(crec, st, CRec::PDN, P);
     rec_load<N>(crec, st, CRec::RSD, RSD);
     SS_LOAD_FENCE();
 
-    double U[NREG * DB], V[DB * NREG];
-    interface_overlap_vals<URBAN, true, NREG>(L.cfg.min_vegetation_fraction, jlay + 1 >= nlay, vf_up, bf_up,
-                                              false, dcur.g.veg_fraction, dcur.g.building_fraction, U, V);
-    double dn_below[NB], up_below[NB];
-    apply_V_vec<NREG, DB, NS>(V, dn_above, dn_below);
-    mat_vec<N, N>(ABE, dn_below, up_below);
-    SS_UNROLL_N(N)
-    for (int i = 0; i < N; ++i) up_below[i] = up_below[i] + src * SBE[i];
     if (URBAN) {
-      const double roof_a = 1.0 - dcur.roof_emissivity;
-      double exposed_roof_frac;
-      if (jlay < nlay - 1) exposed_roof_frac = ss_max(0.0, dcur.g.building_fraction - bf_up);
-      else exposed_roof_frac = dcur.g.building_fraction;
       double sdn = 0.0, sup = 0.0;
       SS_UNROLL_FULL
-      for (int s = 0; s < NS; ++s) sdn += dn_below[N + s];
-      SS_UNROLL_FULL
-      for (int s = 0; s < NS; ++s) {
-        double acc = 0.0;
-        SS_UNROLL_FULL
-        for (int s2 = 0; s2 < NS; ++s2) acc += (roof_a * lg.hweight[s]) * dn_below[N + s2];
-        acc = acc + src * (lg.hweight[s] * dcur.roof_emission * exposed_roof_frac);
-        up_below[N + s] = acc;
-        sup += acc;
-      }
+      for (int s = 0; s < NS; ++s) { sdn += dn_below[N + s]; sup += up_below[N + s]; }
       PUTL(F_ROOF_IN, sdn);
       PUTL(F_ROOF_NET, sdn - sup);
     } else {
@@ -312,38 +321,8 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
       PUTL(F_ROOF_NET, 0.0);
     }
 
-    // ---- issue group 3 (a_above, source_above), work on group 2 ----
-    double AAB[N * N], SAB[N];
-    rec_load<N * N>(crec, st, CRec::AAB, AAB);
-    rec_load<N>(crec, st, CRec::SAB, SAB);
-    SS_LOAD_FENCE();
-
-    // flux at the base of the layer (forest :547-553, :633-636)
-    mat_vec<N, N>(P, dn_below, dn_above);
-    SS_UNROLL_N(N)
-    for (int i = 0; i < N; ++i) dn_above[i] = dn_above[i] + src * RSD[i];
-
-    // ---- issue group 4 (int_flux), work on group 3 ----
-    double IFLUX[N * N], ISRC[N];
-    rec_load<N * N>(lrec, st, LRec::IFLUX, IFLUX);
-    rec_load<N>(lrec, st, LRec::ISRC, ISRC);
-    SS_LOAD_FENCE();
-
-    mat_vec<N, N>(AAB, dn_above, up_above);
-    SS_UNROLL_N(N)
-    for (int i = 0; i < N; ++i) up_above[i] = up_above[i] + src * SAB[i];
-
-    if (FSEL(F_FLUX_DN_LAYER_TOP)) {
-      PUTL(F_FLUX_DN_LAYER_TOP, vec_sum<N>(dn_below));
-      PUTL(F_FLUX_UP_LAYER_TOP, vec_sum<N>(up_below));
-      PUTL(F_FLUX_DN_LAYER_BASE, vec_sum<N>(dn_above));
-      PUTL(F_FLUX_UP_LAYER_BASE, vec_sum<N>(up_above));
-    }
-    double conv[N];
-    SS_UNROLL_N(N)
-    for (int i = 0; i < N; ++i) conv[i] = dn_below[i] + up_above[i];
-
-    // ---- issue group 1 of the next layer down and its scalars, work on group 4 ----
+    // ---- issue group 3 (a_below, source_below and the scalars of the layer below), work on group 2 ----
+    double ABE[N * N], SBE[N];
     if (jlay > 0) {
       const double* crec_n = L.col + rec_base(jlay - 1, L.maxlay, CRec::NELEM, cu);
       din.load(in, lay - 1, (long)jb + (long)nspec * (lay - 1));
@@ -351,8 +330,50 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
       rec_load<N>(crec_n, st, CRec::SBE, SBE);
     }
     SS_LOAD_FENCE();
-    vf_up = dcur.g.veg_fraction;
-    bf_up = dcur.g.building_fraction;
+
+    // flux at the base of the layer (forest :547-553, :633-636)
+    double conv[N];
+    SS_UNROLL_N(N)
+    for (int i = 0; i < N; ++i) conv[i] = dn_below[i];
+    const double s_top_dn = vec_sum<N>(dn_below), s_top_up = vec_sum<N>(up_below);
+    mat_vec<N, N>(P, dn_below, dn_above);
+    SS_UNROLL_N(N)
+    for (int i = 0; i < N; ++i) dn_above[i] = dn_above[i] + src * RSD[i];
+
+    // ---- issue group 4 (int_flux), work on group 3: the interface at the base ----
+    double IFLUX[N * N], ISRC[N];
+    rec_load<N * N>(lrec, st, LRec::IFLUX, IFLUX);
+    rec_load<N>(lrec, st, LRec::ISRC, ISRC);
+    SS_LOAD_FENCE();
+
+    if (jlay > 0) {
+      cross(din, false, dcur.g.veg_fraction, dcur.g.building_fraction, ABE, SBE, dn_above, dn_below,
+            up_below, up_above);
+    } else {
+      // the ground (forest :464-470, urban :560-567): grey Lambertian emitter, per region
+      const double gem = in.ground_emissivity[cidx], gemission = in.ground_emission[cidx];
+      double frac1[NREG];
+      region_fractions<URBAN, true, NREG>(dcur.g.veg_fraction, dcur.g.building_fraction, frac1);
+      SS_UNROLL_FULL
+      for (int jreg = 0; jreg < NREG; ++jreg) {
+        double sd = 0.0;
+        SS_UNROLL_FULL
+        for (int js = 0; js < NS; ++js) sd += dn_above[js + jreg * NS];
+        SS_UNROLL_FULL
+        for (int js = 0; js < NS; ++js)
+          up_above[js + jreg * NS] = ((1.0 - gem) * lg.hweight[js]) * sd
+                                     + src * ((lg.hweight[js] * frac1[jreg]) * gemission);
+      }
+    }
+
+    if (FSEL(F_FLUX_DN_LAYER_TOP)) {
+      PUTL(F_FLUX_DN_LAYER_TOP, s_top_dn);
+      PUTL(F_FLUX_UP_LAYER_TOP, s_top_up);
+      PUTL(F_FLUX_DN_LAYER_BASE, vec_sum<N>(dn_above));
+      PUTL(F_FLUX_UP_LAYER_BASE, vec_sum<N>(up_above));
+    }
+    SS_UNROLL_N(N)
+    for (int i = 0; i < N; ++i) conv[i] = conv[i] + up_above[i];
 
     double ifl[N];
     mat_vec<N, N>(IFLUX, conv, ifl);

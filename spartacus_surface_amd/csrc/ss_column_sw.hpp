@@ -25,9 +25,7 @@ namespace ss {
 // Adding-method record of one layer in the column scratch [layer][elem][cu]
 template <int N, int D>
 struct SwColRec {
-  static constexpr int AAB = 0;                           // a_above(l)        N x N
-  static constexpr int DAB = AAB + rec_even(N * N);       // d_above(l)        N x D
-  static constexpr int PDN = DAB + rec_even(N * D);       // P = Den^-1 T      N x N
+  static constexpr int PDN = 0;                           // P = Den^-1 T      N x N
   static constexpr int QDN = PDN + rec_even(N * N);       // Q = Den^-1 (R d_above E + S_dn)  N x D
   static constexpr int ABE = QDN + rec_even(N * D);       // a_below(l+1)      N x N (canopy part)
   static constexpr int DBE = ABE + rec_even(N * N);       // d_below(l+1)      N x D (canopy part)
@@ -110,8 +108,7 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
       double R[N * N], T[N * N], Den[N * N], X[N * N];
       rec_load<N * N>(lrec, stride, LRec::R, R);
       rec_load<N * N>(lrec, stride, LRec::T, T);
-      rec_store<N * N>(crec, stride, CRec::AAB, Aab);
-      rec_store<N * D>(crec, stride, CRec::DAB, Dab);
+      SS_LOAD_FENCE(); SS_SCHED_FENCE();   // the loads of E, S_dn, S_up stay where they are written (register pressure)
       // denominator = I - a_above R
       mat_mul<N, N, N>(Aab, R, Den);
       SS_UNROLL_NN(N)
@@ -316,16 +313,62 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
   PUTC(F_TOP_NET, dirpass ? 1.0 * (1.0 - top_albedo) : 1.0 - top_albedo);
   double flux_dn_dir_clear = 1.0 / cos_sza;   // clear-sky direct beam of the direct pass
 
-  // group 1 of the top layer and its scalars; fractions of the layer above
+  // Crossing the interface at the top of layer jl (lower), coming from the base
+  // of the layer above (or the free atmosphere): downward fluxes through V, the
+  // upward flux just below the interface from a_below / d_below of layer jl (and
+  // its exposed roofs), and the upward flux just above it through U.  The last
+  // one is what the reference gets as a_above flux + d_above dir at the base of the
+  // layer above: a_above = (U x I) [a_below (V x I); roof rows], so the product
+  // with the flux vector is formed instead of the matrix, and a_above / d_above
+  // are neither stored by the upward sweep nor read here.
+  // (lo = the four scalars of the lower layer this needs: veg_fraction, building_fraction,
+  // roof_albedo, roof_albedo_dir)
+  auto cross = [&](const double* lo, bool upper_is_sky, double vf_up, double bf_up,
+                   const double* ABE, const double* DBE, const double* dir_ab, const double* diff_ab,
+                   double* dir_below, double* diff_below, double* up_below, double* up_ab) {
+    double U[NREG * DB], V[DB * NREG];
+    interface_overlap_vals<URBAN, false, NREG>(L.cfg.min_vegetation_fraction, upper_is_sky, vf_up, bf_up,
+                                               false, lo[0], lo[1], U, V);
+    SS_UNROLL_FULL
+    for (int jl = 0; jl < DB; ++jl) {
+      double acc = 0.0;
+      SS_UNROLL_FULL
+      for (int ju = 0; ju < NREG; ++ju) acc += SS_E(V, jl, ju, DB) * dir_ab[ju];
+      dir_below[jl] = acc;
+    }
+    apply_V_vec<NREG, DB, NS>(V, diff_ab, diff_below);
+    mat_vec<N, N>(ABE, diff_below, up_below);
+    mat_vec_acc<N, D>(DBE, dir_below, up_below);
+    if (URBAN) {
+      // exposed roof (urban :717-721): a_below / d_below roof blocks
+      const double roof_a = lo[2];
+      const double roof_d = cos_sza * lo[3];
+      SS_UNROLL_FULL
+      for (int s = 0; s < NS; ++s) {
+        // row n+s of a_below is roof_albedo*hweight(s) in every roof column
+        double acc = 0.0;
+        SS_UNROLL_FULL
+        for (int s2 = 0; s2 < NS; ++s2) acc += (roof_a * lg.hweight[s]) * diff_below[N + s2];
+        up_below[N + s] = acc + (roof_d * lg.hweight[s]) * dir_below[DB - 1];
+      }
+    }
+    if (up_ab) apply_U_mat<NREG, DB, NS, 1>(U, up_below, up_below + N, up_ab);
+  };
+
+  // top layer: its scalars and group 1 (a_below, d_below), then the interface to the free atmosphere
   SwDownIn<URBAN, NREG> din;
-  double ABE[N * N], DBE[N * D];
-  double vf_up = 0.0, bf_up = 0.0;
+  double dir_below[DB], diff_below[NB], up_below[NB];
+  double bf_up = 0.0;          // building fraction of the layer above (roof / sunlit bookkeeping)
   if (nlay > 0) {
     const int jlay = nlay - 1;
     const double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
+    double ABE[N * N], DBE[N * D];
     din.load(in, l0 + jlay, jb, itransp, nspec);
     rec_load<N * N>(crec, st, CRec::ABE, ABE);
     rec_load<N * D>(crec, st, CRec::DBE, DBE);
+    SS_LOAD_FENCE();
+    const double lo[4] = {din.g.veg_fraction, din.g.building_fraction, din.roof_albedo, din.roof_albedo_dir};
+    cross(lo, true, 0.0, 0.0, ABE, DBE, dir_above, diff_above, dir_below, diff_below, up_below, nullptr);
   }
 
   for (int jlay = nlay - 1; jlay >= 0; --jlay) {
@@ -336,45 +379,16 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
     const SwDownIn<URBAN, NREG> dcur = din;
     const LayerGeom g = dcur.g;
 
-    // ---- issue group 2 (E, d_above, Q), work on group 1 (a_below, d_below) ----
-    double E[D * D], DAB[N * D], Q[N * D];
+    // ---- issue group 2 (E, Q), work on the fluxes just below the top interface ----
+    double E[D * D], Q[N * D];
     rec_load<D * D>(lrec, st, LRec::EDIR, E);
-    rec_load<N * D>(crec, st, CRec::DAB, DAB);
     rec_load<N * D>(crec, st, CRec::QDN, Q);
     SS_LOAD_FENCE();
 
-    double U[NREG * DB], V[DB * NREG];
-    interface_overlap_vals<URBAN, false, NREG>(L.cfg.min_vegetation_fraction, jlay + 1 >= nlay, vf_up, bf_up,
-                                               false, g.veg_fraction, g.building_fraction, U, V);
-    // across the interface at the top of the layer
-    double dir_below[DB], diff_below[NB], up_below[NB];
-    SS_UNROLL_FULL
-    for (int jl = 0; jl < DB; ++jl) {
-      double acc = 0.0;
-      SS_UNROLL_FULL
-      for (int ju = 0; ju < NREG; ++ju) acc += SS_E(V, jl, ju, DB) * dir_above[ju];
-      dir_below[jl] = acc;
-    }
-    apply_V_vec<NREG, DB, NS>(V, diff_above, diff_below);
-    mat_vec<N, N>(ABE, diff_below, up_below);
-    mat_vec_acc<N, D>(DBE, dir_below, up_below);
     if (URBAN) {
-      // exposed roof (urban :717-721): a_below / d_below roof blocks
-      const double roof_a = dcur.roof_albedo;
-      const double roof_d = cos_sza * dcur.roof_albedo_dir;
-      double sdn = 0.0;
+      double sdn = 0.0, sup = 0.0;
       SS_UNROLL_FULL
-      for (int s = 0; s < NS; ++s) sdn += diff_below[N + s];
-      double sup = 0.0;
-      SS_UNROLL_FULL
-      for (int s = 0; s < NS; ++s) {
-        // row n+s of a_below is roof_albedo*hweight(s) in every roof column
-        double acc = 0.0;
-        SS_UNROLL_FULL
-        for (int s2 = 0; s2 < NS; ++s2) acc += (roof_a * lg.hweight[s]) * diff_below[N + s2];
-        up_below[N + s] = acc + (roof_d * lg.hweight[s]) * dir_below[DB - 1];
-        sup += up_below[N + s];
-      }
+      for (int s = 0; s < NS; ++s) { sdn += diff_below[N + s]; sup += up_below[N + s]; }
       const double roof_in_dir = cos_sza * dir_below[DB - 1];
       PUTL(F_ROOF_IN_DIR, roof_in_dir);
       PUTL(F_ROOF_IN, roof_in_dir + sdn);
@@ -405,39 +419,67 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
       SS_UNROLL_FULL
       for (int r = 0; r < D; ++r) { dir_above[r] = t[r]; dir_conv[r] = dir_below[r] - t[r]; }
     }
-    double refl_dir[N], t3[N];
-    mat_vec<N, D>(DAB, dir_above, refl_dir);
+    double t3[N];
     mat_vec<N, D>(Q, dir_below, t3);
 
-    // ---- issue group 4 (a_above, int_dir), work on group 3 ----
-    double AAB[N * N], IDIR[D * D];
-    rec_load<N * N>(crec, st, CRec::AAB, AAB);
+    // ---- issue group 4 (a_below, d_below and the scalars of the layer below; int_dir), work on group 3 ----
+    double ABE[N * N], DBE[N * D], IDIR[D * D];
+    double lo[4] = {0.0, 0.0, 0.0, 0.0};
+    if (jlay > 0) {
+      const double* crec_n = L.col + rec_base(jlay - 1, L.maxlay, CRec::NELEM, cu);
+      if (NREG > 1) lo[0] = in.veg_fraction[lay - 1];
+      if (URBAN) {
+        lo[1] = in.building_fraction[lay - 1];
+        lo[2] = in.roof_albedo[sidx - nspec];
+        lo[3] = in.roof_albedo_dir[sidx - nspec];
+      }
+      rec_load<N * N>(crec_n, st, CRec::ABE, ABE);
+      rec_load<N * D>(crec_n, st, CRec::DBE, DBE);
+    }
     rec_load<D * D>(lrec, st, LRec::IDIR, IDIR);
     SS_LOAD_FENCE();
 
     // flux at the base of the layer: diff = P diff_top + Q dir_top
+    double conv[N];       // diff_below - up_below at the top, completed below
+    SS_UNROLL_N(N)
+    for (int i = 0; i < N; ++i) conv[i] = diff_below[i] - up_below[i];
+    double s_top_dir = 0.0;
+    SS_UNROLL_FULL
+    for (int r = 0; r < NREG; ++r) s_top_dir += dir_below[r];
+    const double s_top_dn = vec_sum<N>(diff_below), s_top_up = vec_sum<N>(up_below);
     mat_vec<N, N>(P, diff_below, diff_above);
     SS_UNROLL_N(N)
     for (int i = 0; i < N; ++i) diff_above[i] = diff_above[i] + t3[i];
 
-    // ---- issue group 5 (int_diff), work on group 4 ----
+    // ---- group 4: the interface at the base ----
+    if (jlay > 0) {
+      cross(lo, false, g.veg_fraction, g.building_fraction, ABE, DBE, dir_above, diff_above,
+            dir_below, diff_below, up_below, up_above);
+    } else {
+      // the ground (forest :479-484, urban :612-617): Lambertian, per region
+      const double ga = in.ground_albedo[cidx], gad = in.ground_albedo_dir[cidx];
+      SS_UNROLL_FULL
+      for (int jreg = 0; jreg < NREG; ++jreg) {
+        double sd = 0.0;
+        SS_UNROLL_FULL
+        for (int js = 0; js < NS; ++js) sd += diff_above[js + jreg * NS];
+        SS_UNROLL_FULL
+        for (int js = 0; js < NS; ++js)
+          up_above[js + jreg * NS] = (ga * lg.hweight[js]) * sd + (cos_sza * gad * lg.hweight[js]) * dir_above[jreg];
+      }
+    }
+
+    // ---- issue group 5 (int_diff) ----
     double IDIFF[N * N];
     rec_load<N * N>(lrec, st, LRec::IDIFF, IDIFF);
     SS_LOAD_FENCE();
 
-    mat_vec<N, N>(AAB, diff_above, up_above);
-    SS_UNROLL_N(N)
-    for (int i = 0; i < N; ++i) up_above[i] = up_above[i] + refl_dir[i];
-
     if (FSEL(F_FLUX_DN_LAYER_TOP)) {
-      double s = 0.0;
-      SS_UNROLL_FULL
-      for (int r = 0; r < NREG; ++r) s += dir_below[r];
-      const double ddt = cos_sza * s;
+      const double ddt = cos_sza * s_top_dir;
       PUTL(F_FLUX_DN_DIR_LAYER_TOP, ddt);
-      PUTL(F_FLUX_DN_LAYER_TOP, ddt + vec_sum<N>(diff_below));
-      PUTL(F_FLUX_UP_LAYER_TOP, vec_sum<N>(up_below));
-      s = 0.0;
+      PUTL(F_FLUX_DN_LAYER_TOP, ddt + s_top_dn);
+      PUTL(F_FLUX_UP_LAYER_TOP, s_top_up);
+      double s = 0.0;
       SS_UNROLL_FULL
       for (int r = 0; r < NREG; ++r) s += dir_above[r];
       const double ddb = cos_sza * s;
@@ -445,22 +487,16 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
       PUTL(F_FLUX_DN_LAYER_BASE, ddb + vec_sum<N>(diff_above));
       PUTL(F_FLUX_UP_LAYER_BASE, vec_sum<N>(up_above));
     }
-    double int_flux_dir[D], conv[N];
+    double int_flux_dir[D];
     mat_vec<D, D>(IDIR, dir_conv, int_flux_dir);
     SS_UNROLL_N(N)
-    for (int i = 0; i < N; ++i) conv[i] = diff_below[i] - diff_above[i] - up_below[i] + up_above[i];
+    for (int i = 0; i < N; ++i) conv[i] = conv[i] - diff_above[i] + up_above[i];
 
-    // ---- issue group 6 (int_dir_diff) and group 1 of the next layer down, work on group 5 ----
+    // ---- issue group 6 (int_dir_diff), work on group 5 ----
     double IDD[N * D];
     rec_load<N * D>(lrec, st, LRec::IDD, IDD);
-    if (jlay > 0) {
-      const double* crec_n = L.col + rec_base(jlay - 1, L.maxlay, CRec::NELEM, cu);
-      din.load(in, lay - 1, jb, itransp, nspec);
-      rec_load<N * N>(crec_n, st, CRec::ABE, ABE);
-      rec_load<N * D>(crec_n, st, CRec::DBE, DBE);
-    }
+    if (jlay > 0) din.load(in, lay - 1, jb, itransp, nspec);
     SS_LOAD_FENCE();
-    vf_up = g.veg_fraction;
     bf_up = g.building_fraction;
 
     // integrated fluxes (forest :598-606)

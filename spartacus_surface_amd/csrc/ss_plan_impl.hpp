@@ -76,7 +76,7 @@ inline int col_nelem(bool lw, const ClassKey& k) {
   const int n = k.nreg * k.ns, d = k.nreg;
   // = LwColRec<n>::NELEM / SwColRec<n,d>::NELEM (ss_column_lw.hpp, ss_column_sw.hpp)
   auto ev = [](int x) { return (x + 1) & ~1; };
-  return lw ? 3 * ev(n * n) + 3 * ev(n) : 3 * ev(n * n) + 3 * ev(n * d);
+  return lw ? 2 * ev(n * n) + 2 * ev(n) : 2 * ev(n * n) + 2 * ev(n * d);
 }
 
 // Runtime (urban, nreg, ns) -> template instance
