@@ -2,12 +2,12 @@
 // adding method upward (section 4 of spartacus_forest_sw,
 // radsurf_forest_sw.F90:463-528 / spartacus_urban_sw, radsurf_urban_sw.F90:591-674)
 // and the two downward flux passes (section 5, forest :530-760 / urban
-// :676-984).  The adding-method matrices of every layer (a_above, d_above,
-// LU of the denominator, a_below, d_below) go through the column scratch
-// [layer][elem][cu].
+// :676-984).  What the downward sweep needs of the adding method (a_below,
+// d_below and the operators P, Q that take the fluxes from the top to the base
+// of a layer) goes through the column scratch [tile][layer][elem pair][lane].
 //
-// Two kernels: k_up (matrix-matrix work, one wave per SIMD) and k_down (both
-// flux passes in one sweep, matrix-vector work only, several waves per SIMD).
+// Two kernels: k_column (upward, matrix-matrix work) and k_down (both flux
+// passes in one sweep, matrix-vector work only), one wave per SIMD each.
 // Measured alternative: recomputing denominator /
 // a_below / d_below in the downward sweep instead of storing them loads fewer
 // doubles but needs > 256 live fp64 values per lane at n = 6 and spills more
