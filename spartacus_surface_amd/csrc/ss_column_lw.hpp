@@ -207,6 +207,12 @@ constexpr int lw_down_slot(int F) {
 }
 constexpr int kLwDownSlotField[7] = {F_CLEAR_AIR_ABS, F_VEG_ABS, F_VEG_AIR_ABS, F_WALL_IN, F_WALL_NET,
                                      F_ROOF_IN, F_ROOF_NET};
+constexpr bool lw_down_slots_consistent() {
+  for (int s = 0; s < 7; ++s)
+    if (lw_down_slot(kLwDownSlotField[s]) != s) return false;
+  return true;
+}
+static_assert(lw_down_slots_consistent(), "kLwDownSlotField must be the inverse of lw_down_slot");
 
 template <bool URBAN, int NREG, int NS>
 SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {

@@ -255,6 +255,12 @@ constexpr int sw_down_slot(int F) {
 }
 constexpr int kSwDownSlotField[10] = {F_CLEAR_AIR_ABS, F_VEG_ABS, F_VEG_AIR_ABS, F_VEG_ABS_DIR, F_WALL_IN,
                                       F_WALL_NET, F_ROOF_IN, F_ROOF_NET, F_WALL_IN_DIR, F_ROOF_IN_DIR};
+constexpr bool sw_down_slots_consistent() {
+  for (int s = 0; s < 10; ++s)
+    if (sw_down_slot(kSwDownSlotField[s]) != s) return false;
+  return true;
+}
+static_assert(sw_down_slots_consistent(), "kSwDownSlotField must be the inverse of sw_down_slot");
 
 // ---- section 5: the downward flux passes (k_down) ----
 // One lane = (column, band, pass): pass 0 is normalised by the direct flux at
