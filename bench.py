@@ -84,15 +84,60 @@ def cpu_baseline(workload, ncol_sample):
     case = make_case(workload, ncol_sample, 12345)
     a = (case["config"], case["canopy"], case["sw"], case["lw"])
     if checker.have_ref():
-        _, sec = checker.run_ref(*a, want_profiles=False, nblocksize=16, nrepeat=1)
+        ref_out, sec = checker.run_ref(*a, want_profiles=False, nblocksize=16, nrepeat=1)
         kind = "reference"
     else:
-        _, sec = checker.run_oracle(*a, want_profiles=False, nthreads=cores)
+        ref_out, sec = checker.run_oracle(*a, want_profiles=False, nthreads=cores)
         kind = "port"
-    return {"value": ncol_sample / sec, "unit": "columns/s", "cores": cores, "kind": kind,
+    base = {"value": ncol_sample / sec, "unit": "columns/s", "cores": cores, "kind": kind,
             "sample": "%d columns of the bench workload (%s), %.1f s, %s"
                       % (ncol_sample, workload, sec, "flang -O2 OpenMP dynamic nblocksize=16"
                          if kind == "reference" else "gcc -O2 OpenMP C port")}
+    return base, parity_of_sample(case, ref_out, kind)
+
+
+def parity_of_sample(case, ref_out, kind):
+    """The second half of BASELINE.json's metric: max relative |flux difference| between
+    the GPU path and the CPU checker on the sample the CPU baseline just computed (every
+    member of bc_out and of the four flux objects; error metric of tests/fixture_io.py)."""
+    from spartacus_surface_amd import radsurf
+    from oracle import checker
+    from tests import fixture_io
+    cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
+    plan = radsurf.Plan(cfg, cp, sw, lw, want_profiles=False)
+    plan.solve()
+    out = checker.alloc_outputs(cfg, cp, False)
+    plan.download(out["bc_out"], out["sw_norm_dir"], out["sw_norm_diff"], out["lw_internal"], out["lw_norm"])
+    plan.close()
+    errs = fixture_io.rel_errors(fixture_io.flatten_outputs(out), fixture_io.flatten_outputs(ref_out))
+    worst = max(errs, key=errs.get)
+    over = {k: v for k, v in errs.items() if v > 1.0e-5}
+    res = {"max_rel_error": errs[worst], "where": worst, "against": kind, "columns": int(cp.ncol),
+           "variables": len(errs), "above_1e-5": over,
+           "note": "relative to max(|ref|, 1e-3 max|ref| of the variable); for the variables above 1e-5 "
+                   "(if any) 'worst_elements' gives the column of the worst element and the CPU "
+                   "restatement's own distance from exact arithmetic (same algorithm in binary128) at "
+                   "that element: the parity bar of the test-suite is max(1e-5, 4 x reference noise) "
+                   "(DESIGN.md section 2)"}
+    if over:
+        # where is the worst element of each such variable, and how far is the
+        # CPU restatement itself from exact arithmetic in that very column?
+        g, r = fixture_io.flatten_outputs(out), fixture_io.flatten_outputs(ref_out)
+        detail = {}
+        for k in over:
+            den = np.maximum(np.abs(r[k]), 1.0e-3 * float(np.max(np.abs(r[k]))))
+            e = np.abs(g[k] - r[k]) / den
+            idx = np.unravel_index(int(np.argmax(e)), e.shape)
+            per_col = r[k].shape[0] == cp.ncol
+            col = int(idx[0]) if per_col else int(np.searchsorted(cp.istartlay - 1, idx[0], side="right") - 1)
+            f64 = fixture_io.flatten_outputs(checker.run_oracle(cfg, cp, sw, lw, want_profiles=False,
+                                                                istartcol=col + 1, iendcol=col + 1)[0])
+            f128 = fixture_io.flatten_outputs(checker.run_oracle(cfg, cp, sw, lw, want_profiles=False,
+                                                                 istartcol=col + 1, iendcol=col + 1, quad=True)[0])
+            detail[k] = {"column": col, "error": float(e[idx]),
+                         "reference_noise_there": float(abs(f64[k][idx] - f128[k][idx]) / den[idx])}
+        res["worst_elements"] = detail
+    return res
 
 
 def measured_traffic(family, cols_per_launch, workload="c3"):
@@ -326,7 +371,7 @@ def main():
         if world == 1 and not args.no_extras and case.get("top_flux_dn_sw") is not None:
             line["scale_sum"] = scale_sum_rate(plan, case, args.columns)
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
-            line["cpu_baseline"] = cpu_baseline(args.workload, min(args.cpu_sample, args.columns))
+            line["cpu_baseline"], line["parity"] = cpu_baseline(args.workload, min(args.cpu_sample, args.columns))
             line["pcie_inclusive"] = host_entry_rate(min(args.columns, 200_000))
         print(json.dumps(line), flush=True)
     plan.close()
