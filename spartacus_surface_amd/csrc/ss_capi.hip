@@ -70,6 +70,15 @@ __global__ void __launch_bounds__(256) k_simple_urban(const ss::MiscLaunch M) {
   const int nmax = M.nsw > M.nlw ? M.nsw : M.nlw;
   if (u < (long)M.ncols * nmax) ss::simple_urban_unit(M, (int)u);
 }
+// input pack (ss_pack.hpp): block -> (tile, layer) with the XCD-aware order of k_layer, so that the
+// layers of a tile, which share the input lines, run in the same L2 at the same time
+__global__ void __launch_bounds__(64) k_pack(const ss::PackLaunch P) {
+  const int per_group = 8 * P.maxlay;
+  const int group = blockIdx.x / per_group, r = blockIdx.x % per_group;
+  const int tile = group * 8 + (r & 7), jlay = r >> 3;
+  const int cu = tile * 64 + threadIdx.x;
+  if (cu < P.ncu) ss::pack_unit(P, cu, jlay);
+}
 __global__ void __launch_bounds__(256) k_spectrum_col(const ss::SpectrumLaunch S) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < S.ncols) ss::spectrum_col_unit(S, i);
@@ -190,6 +199,15 @@ struct HipBackend {
     hipEvent_t a = t.next(), b = t.next();
     hipEventRecord(a, stream());
     hipLaunchKernelGGL(k_simple_urban, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream(), M);
+    hipEventRecord(b, stream());
+    t.spans.push_back({FAM_MISC, a, b});
+  }
+  static void launch_pack(const ss::PackLaunch& P, Timers& t) {
+    if (P.ncu <= 0 || P.maxlay <= 0) return;
+    const unsigned tiles = (unsigned)((P.ncu + 63) / 64);
+    hipEvent_t a = t.next(), b = t.next();
+    hipEventRecord(a, stream());
+    hipLaunchKernelGGL(k_pack, dim3(((tiles + 7) / 8) * 8 * (unsigned)P.maxlay), dim3(64), 0, stream(), P);
     hipEventRecord(b, stream());
     t.spans.push_back({FAM_MISC, a, b});
   }

@@ -10,6 +10,7 @@
 #include "ss_layer_matrices.hpp"
 #include "ss_linalg.hpp"
 #include "ss_solver_lw.hpp"
+#include "ss_pack.hpp"
 
 namespace ss {
 
@@ -117,16 +118,20 @@ SS_HD void column_up_lw(const Launch& L, int cu) {
     }
     {
       double U[NREG * DB], V[DB * NREG];
-      interface_overlap<URBAN, true, NREG>(L, col, jlay, U, V);
+      const double* prec = pack_rec(L, jlay, cu, kPackLw);
+      double vf_lo, bf_lo, vf_up = 0.0, bf_up = 0.0;
+      pack_fractions(prec, vf_lo, bf_lo);
+      if (jlay + 1 < nlay) pack_fractions(pack_rec(L, jlay + 1, cu, kPackLw), vf_up, bf_up);
+      interface_overlap_vals<URBAN, true, NREG>(L.cfg.min_vegetation_fraction, jlay + 1 >= nlay, vf_up, bf_up,
+                                                false, vf_lo, bf_lo, U, V);
       double roof_a = 0.0, roof_emis = 0.0, exposed_roof_frac = 0.0;
       if (URBAN) {
         // urban :587-605
-        if (jlay < nlay - 1)
-          exposed_roof_frac = ss_max(0.0, in.building_fraction[lay] - in.building_fraction[lay + 1]);
-        else
-          exposed_roof_frac = in.building_fraction[lay];
-        roof_a = 1.0 - in.roof_emissivity[sidx];
-        roof_emis = in.roof_emission[sidx];
+        if (jlay < nlay - 1) exposed_roof_frac = ss_max(0.0, bf_lo - bf_up);
+        else exposed_roof_frac = bf_lo;
+        const RecPair re = rec_pair_load(prec + 14 * kRecStride);   // roof_emissivity, roof_emission
+        roof_a = 1.0 - re.x;
+        roof_emis = re.y;
       }
       double tA[N * N], tAroof[NS * N];
       SS_UNROLL_FULL
@@ -296,7 +301,7 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
     const int jlay = nlay - 1;
     const double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
     double ABE[N * N], SBE[N];
-    din.load(in, l0 + jlay, (long)jb + (long)nspec * (l0 + jlay));
+    din.load_pack(pack_rec(L, jlay, cu, kPackLw));
     rec_load<N * N>(crec, st, CRec::ABE, ABE);
     rec_load<N>(crec, st, CRec::SBE, SBE);
     SS_LOAD_FENCE();
@@ -331,7 +336,7 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
     double ABE[N * N], SBE[N];
     if (jlay > 0) {
       const double* crec_n = L.col + rec_base(jlay - 1, L.maxlay, CRec::NELEM, cu);
-      din.load(in, lay - 1, (long)jb + (long)nspec * (lay - 1));
+      din.load_pack(pack_rec(L, jlay - 1, cu, kPackLw));
       rec_load<N * N>(crec_n, st, CRec::ABE, ABE);
       rec_load<N>(crec_n, st, CRec::SBE, SBE);
     }

@@ -19,6 +19,7 @@
 #include "ss_layer_matrices.hpp"
 #include "ss_linalg.hpp"
 #include "ss_solver_sw.hpp"
+#include "ss_pack.hpp"
 
 namespace ss {
 
@@ -152,11 +153,17 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
     // overlap to the base of the layer above (forest :495-503, urban :645-653)
     {
       double U[NREG * DB], V[DB * NREG];
-      interface_overlap<URBAN, false, NREG>(L, col, jlay, U, V);
+      const double* prec = pack_rec(L, jlay, cu, kPackSw);
+      double vf_lo, bf_lo, vf_up = 0.0, bf_up = 0.0;
+      pack_fractions(prec, vf_lo, bf_lo);
+      if (jlay + 1 < nlay) pack_fractions(pack_rec(L, jlay + 1, cu, kPackSw), vf_up, bf_up);
+      interface_overlap_vals<URBAN, false, NREG>(L.cfg.min_vegetation_fraction, jlay + 1 >= nlay, vf_up, bf_up,
+                                                 false, vf_lo, bf_lo, U, V);
       double roof_a = 0.0, roof_d = 0.0;
       if (URBAN) {
-        roof_a = in.roof_albedo[sidx];
-        roof_d = cos_sza * in.roof_albedo_dir[sidx];
+        const RecPair ra = rec_pair_load(prec + 8 * kRecStride);   // roof_albedo, roof_albedo_dir
+        roof_a = ra.x;
+        roof_d = cos_sza * ra.y;
       }
       // tA = a_below (V (x) I): canopy rows (N x N) and roof rows (NS x N)
       double tA[N * N], tAroof[NS * N];
@@ -234,6 +241,19 @@ struct SwDownIn {
     veg_ssa = (NREG > 1) ? in.veg_ssa[sidx] : 0.0;
     air_ext_t = in.air_ext[tidx];
     veg_ssa_t = (NREG > 1) ? in.veg_ssa[tidx] : 0.0;
+  }
+  // The same from the input pack (ss_pack.hpp).  The *_t members (band itransp) are
+  // only used by the lane whose band IS itransp (sunlit fractions), for which they
+  // equal its own air_ext / veg_ssa.
+  SS_HD void load_pack(const double* prec) {
+    double v[kPackSw];
+    rec_load<kPackSw>(prec, kRecStride, 0, v);
+    g.dz = v[0]; g.veg_fraction = v[1]; g.veg_scale = v[2]; g.veg_ext = v[3];
+    g.veg_fsd = v[4]; g.building_fraction = v[5]; g.building_scale = v[6]; g.veg_contact_fraction = v[7];
+    roof_albedo = v[8]; roof_albedo_dir = v[9]; wall_albedo = v[10];
+    air_ext = v[11]; air_ssa = v[12]; veg_ssa = v[13];
+    air_ext_t = air_ext;
+    veg_ssa_t = veg_ssa;
   }
 };
 
@@ -369,7 +389,7 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
     const int jlay = nlay - 1;
     const double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
     double ABE[N * N], DBE[N * D];
-    din.load(in, l0 + jlay, jb, itransp, nspec);
+    din.load_pack(pack_rec(L, jlay, cu, kPackSw));
     rec_load<N * N>(crec, st, CRec::ABE, ABE);
     rec_load<N * D>(crec, st, CRec::DBE, DBE);
     SS_LOAD_FENCE();
@@ -433,12 +453,11 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
     double lo[4] = {0.0, 0.0, 0.0, 0.0};
     if (jlay > 0) {
       const double* crec_n = L.col + rec_base(jlay - 1, L.maxlay, CRec::NELEM, cu);
-      if (NREG > 1) lo[0] = in.veg_fraction[lay - 1];
-      if (URBAN) {
-        lo[1] = in.building_fraction[lay - 1];
-        lo[2] = in.roof_albedo[sidx - nspec];
-        lo[3] = in.roof_albedo_dir[sidx - nspec];
-      }
+      const double* pn = pack_rec(L, jlay - 1, cu, kPackSw);
+      pack_fractions(pn, lo[0], lo[1]);
+      const RecPair ra = rec_pair_load(pn + 8 * kRecStride);   // roof_albedo, roof_albedo_dir
+      lo[2] = ra.x;
+      lo[3] = ra.y;
       rec_load<N * N>(crec_n, st, CRec::ABE, ABE);
       rec_load<N * D>(crec_n, st, CRec::DBE, DBE);
     }
@@ -501,7 +520,7 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
     // ---- issue group 6 (int_dir_diff), work on group 5 ----
     double IDD[N * D];
     rec_load<N * D>(lrec, st, LRec::IDD, IDD);
-    if (jlay > 0) din.load(in, lay - 1, jb, itransp, nspec);
+    if (jlay > 0) din.load_pack(pack_rec(L, jlay - 1, cu, kPackSw));
     SS_LOAD_FENCE();
     bf_up = g.building_fraction;
 

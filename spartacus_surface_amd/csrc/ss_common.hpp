@@ -82,6 +82,9 @@ struct LaneLds<false> {
   SS_HD double get(int) const { return 0.0; }
 };
 
+// doubles per (unit, layer) of the input pack (ss_pack.hpp)
+constexpr int kPackSw = 14, kPackLw = 18;
+
 constexpr double kPi = 3.14159265358979323846;   // radtool/radiation_constants.F90:24
 constexpr double kStefanBoltzmann = 5.67037321e-8;  // radiation_constants.F90:26
 constexpr int kDevMaxStreams = 8;                // instantiated stream counts: 1,2,4,8
@@ -172,6 +175,11 @@ struct Launch {
   int lay_nelem, col_nelem;   // record sizes the plan sized the scratch for (checked at launch)
   double* lay;           // layer-matrix scratch  [tile][layer][elem pair][lane][2]
   double* col;           // adding-method scratch, same tiling
+  // Per-layer inputs of the class, re-laid out once per upload in the tiling of the
+  // scratch records (ss_pack.hpp): unit cu of this launch is unit pack_cu0 + cu of the pack
+  const double* pack;
+  int pack_maxlay;       // layer slots per tile of the pack (largest nlay of the class)
+  int pack_cu0;
   double* top1;          // bc_out: sw_albedo / lw_emissivity   (nspec, ncol)
   double* top2;          // bc_out: sw_albedo_dir / lw_emission (nspec, ncol)
   FluxDev flux_a;        // sw_norm_dir  / lw_internal

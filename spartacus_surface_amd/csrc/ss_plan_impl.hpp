@@ -33,6 +33,7 @@
 
 #include "../../include/spartacus_surface_hip.h"
 #include "ss_common.hpp"
+#include "ss_pack.hpp"
 #include "ss_layer_matrices.hpp"
 #include "ss_misc_units.hpp"
 #include "ss_column_lw.hpp"
@@ -58,6 +59,8 @@ struct ColumnClass {
   std::vector<int32_t> cols;   // 0-based, sorted by nlay descending (stable)
   size_t dev_offset = 0;       // offset of cols in the device index buffer
   int maxlay = 0;
+  double* d_pack = nullptr;    // per-layer inputs in record tiling (ss_pack.hpp), whole class
+  size_t pack_elems = 0;
 };
 
 inline bool key_supported(const ClassKey& k) {
@@ -156,6 +159,8 @@ class Plan {
     dev.clear();
     dev_elems.clear();
     if (d_index) Backend::free(d_index);
+    free_packs(sw_classes);
+    free_packs(lw_classes);
     for (int p = 0; p < kMaxPipes; ++p) {
       if (d_lay[p]) Backend::free(d_lay[p]);
       if (d_col[p]) Backend::free(d_col[p]);
@@ -165,6 +170,48 @@ class Plan {
     if (d_eigen_fail) Backend::free(d_eigen_fail);
     d_index = nullptr; d_eigen_fail = nullptr;
     timers.release();
+  }
+
+  static void free_packs(std::vector<ColumnClass>& cls) {
+    for (auto& c : cls) {
+      if (c.d_pack) Backend::free(c.d_pack);
+      c.d_pack = nullptr;
+      c.pack_elems = 0;
+    }
+  }
+
+  // (Re)build the input packs of all classes from the device mirrors of the inputs
+  bool packs_valid = false;
+  int pack_inputs() {
+    for (int lw = 0; lw < 2; ++lw) {
+      auto& classes = lw ? lw_classes : sw_classes;
+      const int nspec = lw ? nlw : nsw;
+      for (auto& c : classes) {
+        int rc = check_inputs(c.key, lw != 0);
+        if (rc) return rc;
+        const size_t units = c.cols.size() * (size_t)nspec;
+        const size_t tiles = (units + 63) / 64;
+        const size_t need = tiles * 64 * (size_t)c.maxlay * (size_t)(lw ? kPackLw : kPackSw);
+        if (!c.d_pack || c.pack_elems < need) {
+          if (c.d_pack) Backend::free(c.d_pack);
+          c.d_pack = static_cast<double*>(Backend::alloc(need * sizeof(double)));
+          c.pack_elems = need;
+        }
+        PackLaunch P;
+        P.in = make_inputs(lw != 0);
+        P.cols = d_index + c.dev_offset;
+        P.ncu = (int)units;
+        P.nspec = nspec;
+        P.maxlay = c.maxlay;
+        P.lw = lw;
+        P.urban = c.key.urban ? 1 : 0;
+        P.nreg = c.key.nreg;
+        P.pack = c.d_pack;
+        Backend::launch_pack(P, timers);
+      }
+    }
+    packs_valid = true;
+    return SS_OK;
   }
 
   // ---- device mirrors ----
@@ -334,6 +381,13 @@ class Plan {
   }
 
   int classify() {
+    // the pack buffers survive a re-classification with the same classes (a host
+    // that calls every time step): park them by class key, take them back below
+    std::map<std::pair<int, ClassKey>, std::pair<double*, size_t>> pool;
+    for (int lw = 0; lw < 2; ++lw)
+      for (auto& c : (lw ? lw_classes : sw_classes))
+        if (c.d_pack) { pool[{lw, c.key}] = {c.d_pack, c.pack_elems}; c.d_pack = nullptr; }
+    packs_valid = false;
     sw_classes.clear(); lw_classes.clear();
     flat_cols.clear(); night_cols.clear(); simple_cols[0].clear(); simple_cols[1].clear();
     std::map<ClassKey, std::vector<int32_t>> swm, lwm;
@@ -390,6 +444,12 @@ class Plan {
     };
     finish(swm, sw_classes);
     finish(lwm, lw_classes);
+    for (int lw = 0; lw < 2; ++lw)
+      for (auto& c : (lw ? lw_classes : sw_classes)) {
+        auto it = pool.find({lw, c.key});
+        if (it != pool.end()) { c.d_pack = it->second.first; c.pack_elems = it->second.second; pool.erase(it); }
+      }
+    for (auto& kv : pool) Backend::free(kv.second.first);
 
     // one device index buffer: [sw classes][lw classes][flat][night][simple exp][simple inf]
     std::vector<int32_t> idx;
@@ -570,6 +630,9 @@ class Plan {
     L.col_nelem = col_nelem(lw, c.key);
     L.lay = d_lay[pipe];
     L.col = d_col[pipe];
+    L.pack = c.d_pack;
+    L.pack_maxlay = c.maxlay;
+    L.pack_cu0 = (int)(first * (size_t)L.nspec);
     L.top1 = darr(lw ? "bc_out.lw_emissivity" : "bc_out.sw_albedo");
     L.top2 = darr(lw ? "bc_out.lw_emission" : "bc_out.sw_albedo_dir");
     L.flux_a = flux_dev(lw ? "lw_internal" : "sw_norm_dir");
@@ -602,6 +665,10 @@ class Plan {
   int solve() {
     timers.begin_solve();
     Backend::memset_async(d_eigen_fail, 0, kCounters * sizeof(unsigned long long));
+    if (!packs_valid) {      // first solve after an upload (or after the device spectrum changed the LW inputs)
+      int rc = pack_inputs();
+      if (rc) return rc;
+    }
     if (!flat_cols.empty()) {
       if (cfg.do_sw && (!darr("sw.ground_albedo"))) { error = "sw.ground_albedo missing"; return SS_ERR_BAD_ARGUMENT; }
       if (cfg.do_lw && (!darr("lw.ground_emissivity") || !darr("lw.ground_emission"))) { error = "lw ground arrays missing"; return SS_ERR_BAD_ARGUMENT; }
@@ -682,6 +749,7 @@ class Plan {
     S.nlays = (h_istartlay[iendcol - 1] - 1 + h_nlay[iendcol - 1]) - S.lay0;
     if (S.nlays > 0 && (!S.clear_air_temperature || !S.clear_air_planck)) { error = "air temperature / planck arrays missing"; return SS_ERR_BAD_ARGUMENT; }
     Backend::launch_spectrum(S, timers);
+    packs_valid = false;     // emission / Planck arrays of the LW packs are stale now
     return SS_OK;
   }
 

@@ -50,6 +50,16 @@ struct LwLayerIn {
       wall_emission = in.wall_emission[sidx];
     }
   }
+  // The same from the input pack (ss_pack.hpp; rec = pack record of the layer)
+  SS_HD void load_pack(const double* rec) {
+    double v[kPackLw];
+    rec_load<kPackLw>(rec, kRecStride, 0, v);
+    g.dz = v[0]; g.veg_fraction = v[1]; g.veg_scale = v[2]; g.veg_ext = v[3];
+    g.veg_fsd = v[4]; g.building_fraction = v[5]; g.building_scale = v[6]; g.veg_contact_fraction = v[7];
+    air_ext = v[8]; air_ssa = v[9]; veg_ssa = v[10]; veg_planck = v[11];
+    veg_air_planck = v[12]; clear_air_planck = v[13];
+    roof_emissivity = v[14]; roof_emission = v[15]; wall_emissivity = v[16]; wall_emission = v[17];
+  }
 };
 
 template <bool URBAN, int NREG>

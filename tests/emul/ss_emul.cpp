@@ -42,6 +42,10 @@ struct EmulBackend {
     const int nmax = M.nsw > M.nlw ? M.nsw : M.nlw;
     for (int u = 0; u < M.ncols * nmax; ++u) ss::simple_urban_unit(M, u);
   }
+  static void launch_pack(const ss::PackLaunch& P, Timers&) {
+    for (int cu = 0; cu < P.ncu; ++cu)
+      for (int jlay = 0; jlay < P.maxlay; ++jlay) ss::pack_unit(P, cu, jlay);
+  }
   static void launch_spectrum(const ss::SpectrumLaunch& S, Timers&) {
     for (int i = 0; i < S.ncols; ++i) ss::spectrum_col_unit(S, i);
     for (int i = 0; i < S.nlays; ++i) ss::spectrum_lay_unit(S, i);
