@@ -246,8 +246,8 @@ struct SwDownIn {
   // only used by the lane whose band IS itransp (sunlit fractions), for which they
   // equal its own air_ext / veg_ssa.
   SS_HD void load_pack(const double* prec) {
-    double v[kPackSw];
-    rec_load<kPackSw>(prec, kRecStride, 0, v);
+    double v[14];
+    rec_load<14>(prec, kRecStride, 0, v);
     g.dz = v[0]; g.veg_fraction = v[1]; g.veg_scale = v[2]; g.veg_ext = v[3];
     g.veg_fsd = v[4]; g.building_fraction = v[5]; g.building_scale = v[6]; g.veg_contact_fraction = v[7];
     roof_albedo = v[8]; roof_albedo_dir = v[9]; wall_albedo = v[10];

@@ -83,7 +83,7 @@ struct LaneLds<false> {
 };
 
 // doubles per (unit, layer) of the input pack (ss_pack.hpp)
-constexpr int kPackSw = 14, kPackLw = 18;
+constexpr int kPackSw = 16, kPackLw = 18;
 
 constexpr double kPi = 3.14159265358979323846;   // radtool/radiation_constants.F90:24
 constexpr double kStefanBoltzmann = 5.67037321e-8;  // radiation_constants.F90:26

@@ -8,12 +8,13 @@
 // over (~10 KB per column of their 23-30 KB).  The plan therefore re-lays them
 // out once per upload, [tile of 64 units][layer][element pair][lane][2] like the
 // scratch records, and the column kernels read 16-byte pairs from there.
-// (The layer kernels keep reading the caller's arrays: all layers of a tile run
-// at the same time in one L2 there, see k_layer.)
+// The layer kernels read them from there too: the address of a pack record needs
+// no look-up of the column's layer offset, so the inputs arrive with the first
+// round trip of the wave instead of the third.
 //
-//   SW (kPackSw = 14): dz, veg_fraction | veg_scale, veg_ext | veg_fsd, building_fraction |
+//   SW (kPackSw = 16): dz, veg_fraction | veg_scale, veg_ext | veg_fsd, building_fraction |
 //                      building_scale, veg_contact_fraction | roof_albedo, roof_albedo_dir |
-//                      wall_albedo, air_ext | air_ssa, veg_ssa
+//                      wall_albedo, air_ext | air_ssa, veg_ssa | wall_specular_frac, -
 //   LW (kPackLw = 18): the same four geometry pairs | air_ext, air_ssa | veg_ssa, veg_planck |
 //                      veg_air_planck, clear_air_planck | roof_emissivity, roof_emission |
 //                      wall_emissivity, wall_emission
@@ -54,6 +55,7 @@ SS_HD void pack_unit(const PackLaunch& P, int cu, int jlay) {
     rec_pair_store(r + 8 * st, urban ? in.roof_albedo[sidx] : 0.0, urban ? in.roof_albedo_dir[sidx] : 0.0);
     rec_pair_store(r + 10 * st, urban ? in.wall_albedo[sidx] : 0.0, in.air_ext[sidx]);
     rec_pair_store(r + 12 * st, in.air_ssa[sidx], veg ? in.veg_ssa[sidx] : 0.0);
+    rec_pair_store(r + 14 * st, urban ? in.wall_specular_frac[sidx] : 0.0, 0.0);
   } else {
     rec_pair_store(r + 8 * st, in.air_ext[sidx], in.air_ssa[sidx]);
     rec_pair_store(r + 10 * st, veg ? in.veg_ssa[sidx] : 0.0, veg ? in.veg_planck[sidx] : 0.0);

@@ -15,6 +15,7 @@
 #include "ss_geometry.hpp"
 #include "ss_layer_matrices.hpp"
 #include "ss_solver_sw.hpp"
+#include "ss_pack.hpp"
 
 namespace ss {
 
@@ -107,18 +108,21 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay) {
   const int col = L.cols[cu / L.nspec];
   const int jb = cu % L.nspec;
   if (jlay >= in.nlay[col]) return;
-  const int lay = in.istartlay[col] - 1 + jlay;
-  const long sidx = (long)jb + (long)L.nspec * lay;
 
+  // per-layer inputs from the input pack (ss_pack.hpp)
+  LwLayerIn<URBAN, NREG> raw;
+  raw.load_pack(pack_rec(L, jlay, cu, kPackLw));
   LwLayerProps<URBAN, NREG> p;
-  lw_layer_props<URBAN, NREG>(L, lay, sidx, p);
+  lw_layer_props<URBAN, NREG>(L, raw, p);
   double fx[NREG * NREG];
   exchange_rates<NREG>(p.frac, p.np, L.cfg.min_vegetation_fraction, fx);
 
   // wall_ext = 1, wall_factor = 1 - wall_emissivity(1,jlay) - band 1 for all
   // bands (radsurf_urban_lw.F90:390-392)
   const double wall_ext = 1.0;
-  const double wall_factor = URBAN ? 1.0 - in.wall_emissivity[(long)L.nspec * lay] : 0.0;
+  // (band 1 = the pack record of the column's first unit, element 16 = wall_emissivity)
+  const double wall_factor =
+      URBAN ? 1.0 - rec_pair_load(pack_rec(L, jlay, cu - jb, kPackLw) + 16 * kRecStride).x : 0.0;
 
   double g1[N * N], g2[N * N], b[N];
   mat_zero<N, N>(g1);
@@ -171,7 +175,7 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay) {
   SS_UNROLL_FULL
   for (int jreg = 0; jreg < NREG; ++jreg) {
     const double volume_emiss = p.frac[jreg] * (p.ext_reg[jreg] * (1.0 - p.ssa_reg[jreg]) * p.planck_reg[jreg]);
-    const double wall_emiss = URBAN ? p.npw[jreg] * lg.vadjustment * in.wall_emission[sidx] : 0.0;
+    const double wall_emiss = URBAN ? p.npw[jreg] * lg.vadjustment * raw.wall_emission : 0.0;
     SS_UNROLL_FULL
     for (int js = 0; js < NS; ++js) {
       const int ifr = js + jreg * NS;

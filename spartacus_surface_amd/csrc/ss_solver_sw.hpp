@@ -18,6 +18,7 @@
 #include "ss_linalg.hpp"
 #include "ss_geometry.hpp"
 #include "ss_layer_matrices.hpp"
+#include "ss_pack.hpp"
 
 namespace ss {
 
@@ -59,8 +60,6 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay) {
   const int col = L.cols[cu / L.nspec];
   const int jb = cu % L.nspec;
   if (jlay >= in.nlay[col]) return;
-  const int lay = in.istartlay[col] - 1 + jlay;
-  const long sidx = (long)jb + (long)L.nspec * lay;
 
   const double cos_in = in.cos_sza[col];
   const double cos_sza = URBAN ? ss_max(cos_in, 1.0e-6) : cos_in;
@@ -72,7 +71,12 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay) {
     tan0 = sqrt(1.0 - cos_sza * cos_sza) / ss_max(cos_sza, 1.0e-6);
   }
 
-  const LayerGeom g = load_layer_geom<URBAN, NREG>(in, lay);
+  // per-layer inputs from the input pack (ss_pack.hpp)
+  double pk[kPackSw];
+  rec_load<kPackSw>(pack_rec(L, jlay, cu, kPackSw), kRecStride, 0, pk);
+  LayerGeom g;
+  g.dz = pk[0]; g.veg_fraction = pk[1]; g.veg_scale = pk[2]; g.veg_ext = pk[3];
+  g.veg_fsd = pk[4]; g.building_fraction = pk[5]; g.building_scale = pk[6]; g.veg_contact_fraction = pk[7];
   double frac[NREG], np[NREG], npw[NREG], fx[NREG * NREG], od[NREG], f_wall[NREG];
   region_fractions<URBAN, false, NREG>(g.veg_fraction, g.building_fraction, frac);
   norm_perimeters<URBAN, NREG>(L.cfg, g, np, npw);
@@ -86,14 +90,13 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay) {
     SS_UNROLL_FULL
     for (int r = 0; r < NREG; ++r)
       f_wall[r] = (frac[r] <= L.cfg.min_vegetation_fraction) ? 0.0 : npw[r] / (kPi * frac[r]);
-    const double wa = in.wall_albedo[sidx], wsf = in.wall_specular_frac[sidx];
+    const double wa = pk[10], wsf = pk[14];
     wall_ext = 1.0 - wa * wsf;
     wall_factor = wa * (1.0 - wsf);
   }
 
   double ext_reg[NREG], ssa_reg[NREG];
-  region_optics<NREG>(in.air_ext[sidx], in.air_ssa[sidx], g.veg_ext,
-                      (NREG > 1) ? in.veg_ssa[sidx] : 0.0, od, ext_reg, ssa_reg);
+  region_optics<NREG>(pk[11], pk[12], g.veg_ext, pk[13], od, ext_reg, ssa_reg);
 
   // ---- Gamma matrices (forest :329-387, urban :424-497) ----
   double g0[D * D], g1[N * N], g2[N * N], g3[N * D];
