@@ -227,6 +227,7 @@ template <bool URBAN, int NREG>
 struct SwDownIn {
   LayerGeom g;
   double roof_albedo, roof_albedo_dir, wall_albedo, air_ext, air_ssa, veg_ssa, air_ext_t, veg_ssa_t;
+  double wall_specular_frac;
   SS_HD void load(const Inputs& in, int lay, int jb, int itransp, int nspec) {
     const long sidx = (long)jb + (long)nspec * lay, tidx = (long)itransp + (long)nspec * lay;
     g = load_layer_geom<URBAN, NREG>(in, lay);
@@ -241,13 +242,15 @@ struct SwDownIn {
     veg_ssa = (NREG > 1) ? in.veg_ssa[sidx] : 0.0;
     air_ext_t = in.air_ext[tidx];
     veg_ssa_t = (NREG > 1) ? in.veg_ssa[tidx] : 0.0;
+    wall_specular_frac = URBAN ? in.wall_specular_frac[sidx] : 0.0;
   }
   // The same from the input pack (ss_pack.hpp).  The *_t members (band itransp) are
   // only used by the lane whose band IS itransp (sunlit fractions), for which they
   // equal its own air_ext / veg_ssa.
   SS_HD void load_pack(const double* prec) {
-    double v[14];
-    rec_load<14>(prec, kRecStride, 0, v);
+    double v[kPackSw];
+    rec_load<kPackSw>(prec, kRecStride, 0, v);
+    wall_specular_frac = v[14];
     g.dz = v[0]; g.veg_fraction = v[1]; g.veg_scale = v[2]; g.veg_ext = v[3];
     g.veg_fsd = v[4]; g.building_fraction = v[5]; g.building_scale = v[6]; g.veg_contact_fraction = v[7];
     roof_albedo = v[8]; roof_albedo_dir = v[9]; wall_albedo = v[10];
@@ -494,11 +497,6 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
       }
     }
 
-    // ---- issue group 5 (int_diff) ----
-    double IDIFF[N * N];
-    rec_load<N * N>(lrec, st, LRec::IDIFF, IDIFF);
-    SS_LOAD_FENCE();
-
     if (FSEL(F_FLUX_DN_LAYER_TOP)) {
       const double ddt = cos_sza * s_top_dir;
       PUTL(F_FLUX_DN_DIR_LAYER_TOP, ddt);
@@ -517,19 +515,29 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
     SS_UNROLL_N(N)
     for (int i = 0; i < N; ++i) conv[i] = conv[i] - diff_above[i] + up_above[i];
 
-    // ---- issue group 6 (int_dir_diff), work on group 5 ----
-    double IDD[N * D];
-    rec_load<N * D>(lrec, st, LRec::IDD, IDD);
+    // ---- issue: the scalars of the layer below ----
     if (jlay > 0) din.load_pack(pack_rec(L, jlay - 1, cu, kPackSw));
     SS_LOAD_FENCE();
     bf_up = g.building_fraction;
 
-    // integrated fluxes (forest :598-606)
+    // integrated fluxes (forest :598-606): int_diff conv + int_dir_diff dir_conv
+    //   = -(Gamma1 + Gamma2)^-1 (conv + 2 Gamma3 int_flux_dir), see sw_int_flux_system
     double int_flux_diff[N];
-    mat_vec<N, N>(IDIFF, conv, int_flux_diff);
-    mat_vec<N, D>(IDD, dir_conv, t3);
-    SS_UNROLL_N(N)
-    for (int i = 0; i < N; ++i) int_flux_diff[i] = int_flux_diff[i] + t3[i];
+    {
+      double B[N * N], g3[N * D];
+      bool inc[N];
+      sw_int_flux_system<URBAN, NREG, NS>(L, g, dcur.wall_albedo, dcur.wall_specular_frac, dcur.air_ext,
+                                          dcur.air_ssa, dcur.veg_ssa, sin0, B, g3, inc);
+      SS_UNROLL_N(N)
+      for (int i = 0; i < N; ++i) {
+        double s = conv[i];
+        SS_UNROLL_FULL
+        for (int r = 0; r < D; ++r) s += 2.0 * SS_E(g3, i, r, N) * (inc[r * NS] ? int_flux_dir[r] : 0.0);
+        int_flux_diff[i] = inc[i] ? -s : 0.0;
+      }
+      lu_factor<N>(B);
+      lu_solve<N>(B, int_flux_diff);
+    }
 
     // absorption (forest :608-628, urban :758-788)
     const double air_ext = dcur.air_ext, air_ssa = dcur.air_ssa;

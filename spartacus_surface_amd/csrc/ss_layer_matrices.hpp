@@ -54,9 +54,9 @@ struct SwRec {
   static constexpr int SDN = SUP + rec_even(NF * DF);      // trans_dir_diff  NF x DF
   static constexpr int EDIR = SDN + rec_even(NF * DF);     // trans_dir_dir   DF x DF
   static constexpr int IDIR = EDIR + rec_even(DF * DF);    // int_dir         DF x DF
-  static constexpr int IDIFF = IDIR + rec_even(DF * DF);   // int_diff        NF x NF
-  static constexpr int IDD = IDIFF + rec_even(NF * NF);    // int_dir_diff    NF x DF
-  static constexpr int NELEM = IDD + rec_even(NF * DF);
+  // int_diff (NF x NF) and int_dir_diff (NF x DF) are not stored: the downward sweep
+  // applies them as one solve with Gamma1 + Gamma2 (sw_int_flux_system, ss_solver_sw.hpp)
+  static constexpr int NELEM = IDIR + rec_even(DF * DF);
 };
 
 template <int NF>
@@ -359,26 +359,9 @@ SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
     // int_diff = g2i - g1i of the Schur inverse (radtool_schur.F90:45-51), with
     //   g1i = (G1 - G2 G1^-1 G2)^-1,  g2i = g1i G2 G1^-1.
     // Since G1 - G2 G1^-1 G2 = (G1 - G2) G1^-1 (G1 + G2), this is
-    //   g1i (G2 G1^-1 - I) = (G1 + G2)^-1 G1 (G1 - G2)^-1 (G2 - G1) G1^-1 = -(G1 + G2)^-1:
-    // one inverse instead of two inverses, two products and a solve.
-    double t[N * N];
-    {
-      double B[N * N];
-      SS_UNROLL_NN(N)
-      for (int k = 0; k < N * N; ++k) B[k] = g1[k] + g2[k];
-      lu_factor<N>(B);
-      lu_invert<N>(B, t);
-      SS_UNROLL_NN(N)
-      for (int k = 0; k < N * N; ++k) t[k] = -t[k];
-    }
-    put_embedded<NF, NF, N, N, I0, I0>(w, Rec::IDIFF, t);      // int_diff = g2i - g1i
-    // g3i = (g1i - g2i) (g3 g0i);  int_dir_diff = 2 g3i = -2 t (g3 g0i)
-    double u[N * D], v[N * D];
-    mat_mul<N, D, D>(g3, g0i, u);
-    mat_mul<N, N, D>(t, u, v);
-    SS_UNROLL_FULL
-    for (int k = 0; k < N * D; ++k) v[k] = -2.0 * v[k];
-    put_embedded<NF, DF, N, D, I0, R0>(w, Rec::IDD, v);
+    //   g1i (G2 G1^-1 - I) = (G1 + G2)^-1 G1 (G1 - G2)^-1 (G2 - G1) G1^-1 = -(G1 + G2)^-1,
+    // and int_dir_diff = 2 g3i = -2 int_diff (g3 g0i).  Neither is formed here: the
+    // downward sweep applies both to its flux convergences with one solve with G1 + G2.
   }
 
   SS_STAMP(1);

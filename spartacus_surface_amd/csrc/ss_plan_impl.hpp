@@ -73,7 +73,7 @@ inline bool key_supported(const ClassKey& k) {
 inline int lay_nelem(bool lw, const ClassKey& k) {
   const int n = k.nreg * k.ns, d = k.nreg;
   auto ev = [](int x) { return (x + 1) & ~1; };   // blocks start at even elements (16-byte pairs)
-  return lw ? 3 * ev(n * n) + 2 * ev(n) : 3 * ev(n * n) + 3 * ev(n * d) + 2 * ev(d * d);
+  return lw ? 3 * ev(n * n) + 2 * ev(n) : 2 * ev(n * n) + 2 * ev(n * d) + 2 * ev(d * d);
 }
 inline int col_nelem(bool lw, const ClassKey& k) {
   const int n = k.nreg * k.ns, d = k.nreg;

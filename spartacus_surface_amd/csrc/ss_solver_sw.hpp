@@ -210,6 +210,110 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay) {
 #endif
 }
 
+// Gamma1 + Gamma2 (B, N x N) and Gamma3 (g3, N x D) of one layer from its inputs, as
+// layer_unit_sw builds them (forest :329-387, urban :424-497; there Gamma1 already
+// includes + Gamma2, so B = the exchange / extinction part + 2 Gamma2), with the rows
+// and columns outside the layer's sub-problem (3-way branch of layer_unit_sw:
+// clear-sky only / vegetated only / full) replaced by the identity.  The downward
+// sweep uses them for the integrated fluxes: the reference's int_diff is
+// -(Gamma1 + Gamma2)^-1 and int_dir_diff = -2 int_diff Gamma3 Gamma0^-1 (see
+// calc_matrices_sw), so int_diff conv + int_dir_diff dir_conv =
+// -(Gamma1 + Gamma2)^-1 (conv + 2 Gamma3 int_flux_dir): one solve instead of two
+// stored matrices per layer.  inc[i] tells which components belong to the sub-problem.
+template <bool URBAN, int NREG, int NS>
+SS_HD void sw_int_flux_system(const Launch& L, const LayerGeom& g, double wall_albedo, double wall_specular_frac,
+                              double air_ext, double air_ssa, double veg_ssa, double sin0,
+                              double* B, double* g3, bool* inc) {
+  constexpr int N = NREG * NS, D = NREG;
+  double frac[NREG], np[NREG], npw[NREG], fx[NREG * NREG], od[NREG], f_wall[NREG];
+  region_fractions<URBAN, false, NREG>(g.veg_fraction, g.building_fraction, frac);
+  norm_perimeters<URBAN, NREG>(L.cfg, g, np, npw);
+  exchange_rates<NREG>(frac, np, L.cfg.min_vegetation_fraction, fx);
+  od_scaling<NREG>(g.veg_fsd, od);
+  double wall_ext = 0.0, wall_factor = 0.0;
+  SS_UNROLL_FULL
+  for (int r = 0; r < NREG; ++r) f_wall[r] = 0.0;
+  if (URBAN) {
+    SS_UNROLL_FULL
+    for (int r = 0; r < NREG; ++r)
+      f_wall[r] = (frac[r] <= L.cfg.min_vegetation_fraction) ? 0.0 : npw[r] / (kPi * frac[r]);
+    wall_ext = 1.0 - wall_albedo * wall_specular_frac;
+    wall_factor = wall_albedo * (1.0 - wall_specular_frac);
+  }
+  double ext_reg[NREG], ssa_reg[NREG];
+  region_optics<NREG>(air_ext, air_ssa, g.veg_ext, veg_ssa, od, ext_reg, ssa_reg);
+
+  mat_zero<N, N>(B);
+  mat_zero<N, D>(g3);
+  SS_UNROLL_FULL
+  for (int jfr = 0; jfr < NREG; ++jfr) {
+    SS_UNROLL_FULL
+    for (int jto = 0; jto < NREG; ++jto) {
+      if (jfr != jto) {
+        SS_UNROLL_FULL
+        for (int js = 0; js < NS; ++js) {
+          const int ifr = js + jfr * NS, ito = js + jto * NS;
+          SS_E(B, ifr, ifr, N) = SS_E(B, ifr, ifr, N) - L.lg.tan_ang[js] * SS_E(fx, jto, jfr, NREG);
+          SS_E(B, ito, ifr, N) = L.lg.tan_ang[js] * SS_E(fx, jto, jfr, NREG);
+        }
+      }
+    }
+  }
+  SS_UNROLL_FULL
+  for (int jreg = 0; jreg < NREG; ++jreg) {
+    SS_UNROLL_FULL
+    for (int js = 0; js < NS; ++js) {
+      const int ifr = js + jreg * NS;
+      if (URBAN)
+        SS_E(B, ifr, ifr, N) = SS_E(B, ifr, ifr, N) - ext_reg[jreg] / L.lg.mu[js]
+                               - L.lg.tan_ang[js] * f_wall[jreg] * wall_ext;
+      else
+        SS_E(B, ifr, ifr, N) = SS_E(B, ifr, ifr, N) - ext_reg[jreg] / L.lg.mu[js];
+    }
+  }
+  SS_UNROLL_FULL
+  for (int jsfr = 0; jsfr < NS; ++jsfr) {
+    SS_UNROLL_FULL
+    for (int jsto = 0; jsto < NS; ++jsto) {
+      SS_UNROLL_FULL
+      for (int jreg = 0; jreg < NREG; ++jreg) {
+        const int ifr = jsfr + jreg * NS, ito = jsto + jreg * NS;
+        double g2;
+        if (URBAN)
+          g2 = 0.5 * (L.lg.weight[jsto] * ext_reg[jreg] * ssa_reg[jreg] / L.lg.mu[jsfr]
+                      + L.lg.vweight[jsto] * L.lg.tan_ang[jsfr] * f_wall[jreg] * wall_factor);
+        else
+          g2 = 0.5 * L.lg.weight[jsto] * ext_reg[jreg] * ssa_reg[jreg] / L.lg.mu[jsfr];
+        // Gamma1 (as used) = exchange / extinction part + Gamma2, so Gamma1 + Gamma2 adds it twice
+        SS_E(B, ito, ifr, N) = (SS_E(B, ito, ifr, N) + g2) + g2;
+      }
+    }
+  }
+  SS_UNROLL_FULL
+  for (int jreg = 0; jreg < NREG; ++jreg) {
+    SS_UNROLL_FULL
+    for (int js = 0; js < NS; ++js) {
+      const int ito = js + jreg * NS;
+      if (URBAN)
+        SS_E(g3, ito, jreg, N) = 0.5 * (L.lg.weight[js] * ext_reg[jreg] * ssa_reg[jreg]
+                                        + L.lg.vweight[js] * sin0 * f_wall[jreg] * wall_factor);
+      else
+        SS_E(g3, ito, jreg, N) = 0.5 * L.lg.weight[js] * ext_reg[jreg] * ssa_reg[jreg];
+    }
+  }
+  // the sub-problem of this layer (the 3-way branch of layer_unit_sw)
+  const bool clear_only = (NREG == 1) || (g.veg_fraction <= L.cfg.min_vegetation_fraction);
+  const bool veg_only = !clear_only && (frac[0] <= L.cfg.min_vegetation_fraction);
+  SS_UNROLL_FULL
+  for (int i = 0; i < N; ++i) inc[i] = clear_only ? (i < NS) : (veg_only ? (i >= NS) : true);
+  SS_UNROLL_FULL
+  for (int j = 0; j < N; ++j) {
+    SS_UNROLL_FULL
+    for (int i = 0; i < N; ++i)
+      if (!(inc[i] && inc[j])) SS_E(B, i, j, N) = (i == j) ? 1.0 : 0.0;
+  }
+}
+
 // ---- overlap operators (U (x) I_NS), (V (x) I_NS) on the canopy + roof blocks ----
 
 // Interface geometry above layer jlay (0-based; jlay = -1 is the ground):
