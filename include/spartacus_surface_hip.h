@@ -220,9 +220,15 @@ typedef struct ss_flux {
  * calls are serialised per device inside the library.
  * The pointers are HOST pointers; the library stages them to HBM, runs the HIP
  * kernels on the current device and copies the results back.
- * The device plan of the previous call is cached and re-filled when the
- * configuration, the shapes and the column range are the same (a model calling
- * every time step); SPARTACUS_NO_PLAN_CACHE=1 disables that.
+ * The columns of a call are cut into chunks that alternate between two device
+ * plans, so that the upload of one chunk, the kernels of the previous one and
+ * the download of the one before overlap (PCIe is what bounds this entry).  The
+ * two plans persist between calls while the configuration, the profile flag and
+ * the current device stay the same - whatever the shapes and the column range:
+ * their device arrays only grow, and only the slices of [istartcol, iendcol]
+ * cross the bus, so the reference driver's block loop (a different column block
+ * per call, nblocksize << ncol) re-uses them.  SPARTACUS_NO_PLAN_CACHE=1 drops
+ * them after every call, SPARTACUS_HOST_CHUNK=<columns> sets the chunk size.
  * -------------------------------------------------------------------------- */
 int spartacus_radsurf_hip(const ss_config *config, const ss_canopy *canopy,
                           const ss_sw_spectral *sw, const ss_lw_spectral *lw,
@@ -297,10 +303,20 @@ int ss_plan_set_pipes(ss_plan *plan, int32_t npipes);
  * "sw_norm_dir.ground_dn", "bc_out.sw_albedo" (for RCCL gathers). */
 int ss_plan_device_ptr(ss_plan *plan, const char *name, void **ptr,
                        int64_t *nelem);
+/* Device the plan lives on (the device that was current at ss_plan_create).  A
+ * plan owns its HIP streams and events; every ss_plan_* call makes the plan's
+ * device current.  Calls on one plan must not overlap in time (different plans
+ * are independent). */
+int ss_plan_device(ss_plan *plan, int32_t *device);
 int ss_plan_destroy(ss_plan *plan);
+/* Number of device plans the host entry spartacus_radsurf_hip has had to build
+ * so far in this process (diagnostic: block-wise calls must not rebuild them). */
+int ss_host_entry_plan_creations(int64_t *count);
 
 /* Library / device information. */
 int ss_device_count(int32_t *count);
+/* hipSetDevice for plans created from now on and for the host entry; existing
+ * plans stay on their device. */
 int ss_set_device(int32_t device);
 const char *ss_last_error(void);
 const char *ss_version(void);

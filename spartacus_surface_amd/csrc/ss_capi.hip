@@ -34,24 +34,7 @@ bool hip_ok(hipError_t e, const char* what) {
     }                                                                               \
   } while (0)
 
-hipStream_t g_stream = nullptr;
-
-hipStream_t stream() {
-  if (!g_stream) HIP_CHECK_THROW(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-  return g_stream;
-}
-
-// Worker streams of the solve ("pipes" of ss_plan_impl.hpp): pipe 0 is the
-// library's main stream, further pipes fork from it and join it again.
 constexpr int kMaxPipes = 8;
-hipStream_t g_pipe[kMaxPipes] = {};
-hipEvent_t g_fork_ev = nullptr, g_join_ev[kMaxPipes] = {};
-
-hipStream_t pipe_stream(int p) {
-  if (p <= 0) return stream();
-  if (!g_pipe[p]) HIP_CHECK_THROW(hipStreamCreateWithFlags(&g_pipe[p], hipStreamNonBlocking));
-  return g_pipe[p];
-}
 
 // ---- misc kernels ----
 __global__ void __launch_bounds__(256) k_flat(const ss::MiscLaunch M) {
@@ -99,8 +82,21 @@ __global__ void __launch_bounds__(256) k_scale_sum(const ss::ScaleSumLaunch S) {
 
 enum Family { FAM_SW_LAYER = 0, FAM_SW_COLUMN, FAM_LW_LAYER, FAM_LW_COLUMN, FAM_MISC, FAM_SW_DOWN, FAM_LW_DOWN, FAM_COUNT };
 
+// Launch check: a kernel launch reports configuration errors through hipGetLastError
+#define SS_LAUNCH_CHECK() HIP_CHECK_THROW(hipGetLastError())
+
+// Device context of ONE plan: the device it was created on, its main stream and
+// the worker streams ("pipes" of ss_plan_impl.hpp: pipe 0 is the main stream,
+// further pipes fork from it and join it again) with their events.  Nothing here
+// is process-global: two plans never share a stream, and a plan created on device
+// d keeps working after the process makes another device current.
 struct HipBackend {
-  // HIP-event timing of every launch of the last solve, on the plan's stream
+  int device = -1;
+  hipStream_t main_ = nullptr;
+  hipStream_t pipe_[kMaxPipes] = {};
+  hipEvent_t fork_ev_ = nullptr, join_ev_[kMaxPipes] = {};
+
+  // HIP-event timing of every launch of the last solve, on the plan's streams
   struct Timers {
     struct Span { int family; hipEvent_t a, b; };
     std::vector<hipEvent_t> pool;
@@ -117,23 +113,12 @@ struct HipBackend {
       }
       return pool[used++];
     }
-    void begin_solve() {
-      used = 0;
-      spans.clear();
-      t0 = next();
-      t1 = next();
-      have_total = false;
-      HIP_CHECK_THROW(hipEventRecord(t0, stream()));
-    }
-    void end_solve() {
-      HIP_CHECK_THROW(hipEventRecord(t1, stream()));
-      have_total = true;
-    }
     void release() {
       for (auto e : pool) hipEventDestroy(e);
       pool.clear();
       used = 0;
       spans.clear();
+      have_total = false;
     }
     // sum (ms) and launch count of one family after synchronisation
     void query(int family, double* ms, int* count) const {
@@ -154,95 +139,132 @@ struct HipBackend {
     }
   };
 
-  static void* alloc(size_t n) {
+  void init() {
+    if (device < 0) HIP_CHECK_THROW(hipGetDevice(&device));
+  }
+  // make the plan's device current (every entry point of a plan starts here)
+  void activate() const {
+    int cur = -1;
+    if (device >= 0 && (hipGetDevice(&cur) != hipSuccess || cur != device)) HIP_CHECK_THROW(hipSetDevice(device));
+  }
+  void release() {
+    if (device < 0) return;
+    int cur = -1;
+    const bool sw = hipGetDevice(&cur) == hipSuccess && cur != device && hipSetDevice(device) == hipSuccess;
+    for (int p = 0; p < kMaxPipes; ++p) {
+      if (pipe_[p]) hipStreamDestroy(pipe_[p]);
+      if (join_ev_[p]) hipEventDestroy(join_ev_[p]);
+      pipe_[p] = nullptr;
+      join_ev_[p] = nullptr;
+    }
+    if (fork_ev_) hipEventDestroy(fork_ev_);
+    if (main_) hipStreamDestroy(main_);
+    fork_ev_ = nullptr;
+    main_ = nullptr;
+    if (sw) hipSetDevice(cur);
+  }
+  hipStream_t stream() {
+    if (!main_) HIP_CHECK_THROW(hipStreamCreateWithFlags(&main_, hipStreamNonBlocking));
+    return main_;
+  }
+  hipStream_t pipe_stream(int p) {
+    if (p <= 0) return stream();
+    if (!pipe_[p]) HIP_CHECK_THROW(hipStreamCreateWithFlags(&pipe_[p], hipStreamNonBlocking));
+    return pipe_[p];
+  }
+
+  void begin_solve(Timers& t) {
+    t.used = 0;
+    t.spans.clear();
+    t.t0 = t.next();
+    t.t1 = t.next();
+    t.have_total = false;
+    HIP_CHECK_THROW(hipEventRecord(t.t0, stream()));
+  }
+  void end_solve(Timers& t) {
+    HIP_CHECK_THROW(hipEventRecord(t.t1, stream()));
+    t.have_total = true;
+  }
+
+  void* alloc(size_t n) {
     void* p = nullptr;
     HIP_CHECK_THROW(hipMalloc(&p, n ? n : 8));
     return p;
   }
-  static void free(void* p) { if (p) hipFree(p); }
-  static void memset(void* p, int v, size_t n) {
-    HIP_CHECK_THROW(hipMemsetAsync(p, v, n, stream()));
+  void free(void* p) { if (p) hipFree(p); }
+  void memset(void* p, int v, size_t n) { HIP_CHECK_THROW(hipMemsetAsync(p, v, n, stream())); }
+  void memset_async(void* p, int v, size_t n) { HIP_CHECK_THROW(hipMemsetAsync(p, v, n, stream())); }
+  // Copies are queued on the plan's main stream without a synchronisation of their
+  // own: from pageable memory the runtime has staged the host buffer when the call
+  // returns, and the plan synchronises once at the end of upload() / download()
+  // (one wait per call instead of one per array).
+  void h2d(void* d, const void* h, size_t n) {
+    if (n) HIP_CHECK_THROW(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, stream()));
   }
-  static void memset_async(void* p, int v, size_t n) {
-    HIP_CHECK_THROW(hipMemsetAsync(p, v, n, stream()));
+  void d2h(void* h, const void* d, size_t n) {
+    if (n) HIP_CHECK_THROW(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream()));
   }
-  static void h2d(void* d, const void* h, size_t n) {
-    if (n) {
-      HIP_CHECK_THROW(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, stream()));
-      HIP_CHECK_THROW(hipStreamSynchronize(stream()));   // host buffer may be reused at once
-    }
-  }
-  static void d2h(void* h, const void* d, size_t n) {
-    if (n) {
-      HIP_CHECK_THROW(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream()));
-      HIP_CHECK_THROW(hipStreamSynchronize(stream()));
-    }
-  }
-  static void sync() { HIP_CHECK_THROW(hipStreamSynchronize(stream())); }
+  void sync() { HIP_CHECK_THROW(hipStreamSynchronize(stream())); }
 
-  static void launch_flat(const ss::MiscLaunch& M, Timers& t) {
+  template <class K, class A>
+  void timed_launch(Timers& t, K kernel, dim3 grid, dim3 block, const A& arg) {
     hipEvent_t a = t.next(), b = t.next();
-    hipEventRecord(a, stream());
-    hipLaunchKernelGGL(k_flat, dim3((M.ncols + 255) / 256), dim3(256), 0, stream(), M);
-    hipEventRecord(b, stream());
+    HIP_CHECK_THROW(hipEventRecord(a, stream()));
+    hipLaunchKernelGGL(kernel, grid, block, 0, stream(), arg);
+    SS_LAUNCH_CHECK();
+    HIP_CHECK_THROW(hipEventRecord(b, stream()));
     t.spans.push_back({FAM_MISC, a, b});
   }
-  static void launch_night(const ss::MiscLaunch& M, Timers& t) {
-    hipEvent_t a = t.next(), b = t.next();
-    hipEventRecord(a, stream());
-    hipLaunchKernelGGL(k_night, dim3((M.ncols + 255) / 256), dim3(256), 0, stream(), M);
-    hipEventRecord(b, stream());
-    t.spans.push_back({FAM_MISC, a, b});
+  void launch_flat(const ss::MiscLaunch& M, Timers& t) {
+    if (M.ncols <= 0) return;
+    timed_launch(t, k_flat, dim3((M.ncols + 255) / 256), dim3(256), M);
   }
-  static void launch_simple_urban(const ss::MiscLaunch& M, Timers& t) {
+  void launch_night(const ss::MiscLaunch& M, Timers& t) {
+    if (M.ncols <= 0) return;
+    timed_launch(t, k_night, dim3((M.ncols + 255) / 256), dim3(256), M);
+  }
+  void launch_simple_urban(const ss::MiscLaunch& M, Timers& t) {
     const long units = (long)M.ncols * std::max(M.nsw, M.nlw);
-    hipEvent_t a = t.next(), b = t.next();
-    hipEventRecord(a, stream());
-    hipLaunchKernelGGL(k_simple_urban, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, stream(), M);
-    hipEventRecord(b, stream());
-    t.spans.push_back({FAM_MISC, a, b});
+    if (units <= 0) return;
+    timed_launch(t, k_simple_urban, dim3((unsigned)((units + 255) / 256)), dim3(256), M);
   }
-  static void launch_pack(const ss::PackLaunch& P, Timers& t) {
+  void launch_pack(const ss::PackLaunch& P, Timers& t) {
     if (P.ncu <= 0 || P.maxlay <= 0) return;
     const unsigned tiles = (unsigned)((P.ncu + 63) / 64);
-    hipEvent_t a = t.next(), b = t.next();
-    hipEventRecord(a, stream());
-    hipLaunchKernelGGL(k_pack, dim3(((tiles + 7) / 8) * 8 * (unsigned)P.maxlay), dim3(64), 0, stream(), P);
-    hipEventRecord(b, stream());
-    t.spans.push_back({FAM_MISC, a, b});
+    timed_launch(t, k_pack, dim3(((tiles + 7) / 8) * 8 * (unsigned)P.maxlay), dim3(64), P);
   }
-  static void launch_scale_sum(const ss::ScaleSumLaunch& S, Timers& t) {
+  void launch_scale_sum(const ss::ScaleSumLaunch& S, Timers& t) {
     const long nmax = ((long)S.nspec * std::max(S.ncols, S.nlays)) / 2 + 1;
     if (S.ncols <= 0) return;
     const unsigned gx = (unsigned)std::min<long>((nmax + 255) / 256, 1L << 20);
-    hipEvent_t a = t.next(), b = t.next();
-    hipEventRecord(a, stream());
-    hipLaunchKernelGGL(k_scale_sum, dim3(gx, 4), dim3(256), 0, stream(), S);
-    hipEventRecord(b, stream());
-    t.spans.push_back({FAM_MISC, a, b});
+    timed_launch(t, k_scale_sum, dim3(gx, 4), dim3(256), S);
   }
-  static void launch_spectrum(const ss::SpectrumLaunch& S, Timers&) {
-    if (S.ncols > 0)
+  void launch_spectrum(const ss::SpectrumLaunch& S, Timers&) {
+    if (S.ncols > 0) {
       hipLaunchKernelGGL(k_spectrum_col, dim3((S.ncols + 255) / 256), dim3(256), 0, stream(), S);
-    if (S.nlays > 0)
+      SS_LAUNCH_CHECK();
+    }
+    if (S.nlays > 0) {
       hipLaunchKernelGGL(k_spectrum_lay, dim3((S.nlays + 255) / 256), dim3(256), 0, stream(), S);
-  }
-  // the pipes start after everything queued on the main stream so far ...
-  static void fork(int npipes) {
-    if (npipes <= 1) return;
-    if (!g_fork_ev) HIP_CHECK_THROW(hipEventCreateWithFlags(&g_fork_ev, hipEventDisableTiming));
-    HIP_CHECK_THROW(hipEventRecord(g_fork_ev, stream()));
-    for (int p = 1; p < npipes; ++p) HIP_CHECK_THROW(hipStreamWaitEvent(pipe_stream(p), g_fork_ev, 0));
-  }
-  // ... and the main stream continues after all of them
-  static void join(int npipes) {
-    for (int p = 1; p < npipes; ++p) {
-      if (!g_join_ev[p]) HIP_CHECK_THROW(hipEventCreateWithFlags(&g_join_ev[p], hipEventDisableTiming));
-      HIP_CHECK_THROW(hipEventRecord(g_join_ev[p], pipe_stream(p)));
-      HIP_CHECK_THROW(hipStreamWaitEvent(stream(), g_join_ev[p], 0));
+      SS_LAUNCH_CHECK();
     }
   }
-  static void launch_solver(const ss::ClassKey& key, bool lw, const ss::Launch& L, Timers& t, int pipe) {
+  // the pipes start after everything queued on the main stream so far ...
+  void fork(int npipes) {
+    if (npipes <= 1) return;
+    if (!fork_ev_) HIP_CHECK_THROW(hipEventCreateWithFlags(&fork_ev_, hipEventDisableTiming));
+    HIP_CHECK_THROW(hipEventRecord(fork_ev_, stream()));
+    for (int p = 1; p < npipes; ++p) HIP_CHECK_THROW(hipStreamWaitEvent(pipe_stream(p), fork_ev_, 0));
+  }
+  // ... and the main stream continues after all of them
+  void join(int npipes) {
+    for (int p = 1; p < npipes; ++p) {
+      if (!join_ev_[p]) HIP_CHECK_THROW(hipEventCreateWithFlags(&join_ev_[p], hipEventDisableTiming));
+      HIP_CHECK_THROW(hipEventRecord(join_ev_[p], pipe_stream(p)));
+      HIP_CHECK_THROW(hipStreamWaitEvent(stream(), join_ev_[p], 0));
+    }
+  }
+  void launch_solver(const ss::ClassKey& key, bool lw, const ss::Launch& L, Timers& t, int pipe) {
     ss::SolverLauncher fn = nullptr;
     if (!lw) {
       if (!key.urban) fn = key.nreg == 2 ? ss::launch_sw_forest_r2 : ss::launch_sw_forest_r3;
@@ -252,11 +274,18 @@ struct HipBackend {
       else fn = key.nreg == 1 ? ss::launch_lw_urban_r1 : key.nreg == 2 ? ss::launch_lw_urban_r2 : ss::launch_lw_urban_r3;
     }
     hipEvent_t ev[4] = {t.next(), t.next(), t.next(), t.next()};
-    fn(key.ns, L, pipe_stream(pipe), ev);
+    const int rc = fn(key.ns, L, pipe_stream(pipe), ev);
+    if (rc != 0) {
+      // SS_LAUNCH_BAD_RECORD: the plan's record sizes disagree with the kernels' (a build
+      // inconsistency); anything else is the hipError_t of the failing launch / event record
+      g_last_error = rc == ss::kLaunchBadRecord
+                         ? std::string("scratch record size mismatch between plan and kernels")
+                         : std::string("solver kernel launch: ") + hipGetErrorString((hipError_t)rc);
+      throw (hipError_t)(rc == ss::kLaunchBadRecord ? hipErrorInvalidValue : (hipError_t)rc);
+    }
     t.spans.push_back({lw ? FAM_LW_LAYER : FAM_SW_LAYER, ev[0], ev[1]});
     t.spans.push_back({lw ? FAM_LW_COLUMN : FAM_SW_COLUMN, ev[1], ev[2]});
     t.spans.push_back({lw ? FAM_LW_DOWN : FAM_SW_DOWN, ev[2], ev[3]});
-    HIP_CHECK_THROW(hipGetLastError());
   }
 };
 
@@ -289,6 +318,128 @@ struct ss_plan {
   HipPlan impl;
 };
 
+namespace {
+
+// ---- host entry: column chunks through two alternating device plans ----
+//
+// spartacus_radsurf_hip gets host arrays and must hand host arrays back, so its
+// time is PCIe time: ~2 KB up and ~3.4 KB down per column (C3) against 24 ns of
+// kernels.  The columns of a call are therefore cut into chunks and the chunks
+// alternate between two sub-plans with their own device arrays and streams: while
+// chunk k is solved, chunk k+1 is uploaded and chunk k-1 downloaded, and the host
+// thread only ever waits for copies.  A sub-plan sees a chunk as a column set of
+// its own: every pointer of the caller's structs is advanced to the chunk's first
+// column / first packed layer and istartlay is re-based.  The sub-plans persist
+// between calls (key: configuration, profile flag, device); their device arrays
+// only grow, so a driver that calls with a different column block every time
+// (nblocksize << ncol, driver/spartacus_surface_driver.F90:206-233) re-uses them
+// instead of re-allocating - only the slices of the block cross the bus.
+struct HostEntry {
+  HipPlan* slot[2] = {nullptr, nullptr};
+  ss_config cfg;
+  int profiles = -1, device = -1;
+  long creations = 0;       // sub-plans built so far (tests: block calls must not re-create)
+
+  void drop() {
+    for (auto& p : slot) { delete p; p = nullptr; }
+    profiles = -1;
+    device = -1;
+  }
+};
+HostEntry g_host;           // deliberately never destroyed at process exit (HIP may be gone)
+
+struct ChunkView {
+  ss_canopy can;
+  ss_sw_spectral sw;
+  ss_lw_spectral lw;
+  ss_bc_out bc;
+  ss_flux fl[4];
+  bool have_fl[4];
+  std::vector<int32_t> istartlay;
+};
+
+template <class T>
+T* adv(T* p, long off) { return p ? p + off : nullptr; }
+
+// columns [c0, c1) (0-based) of the caller's objects as objects of their own
+void make_view(const ss_canopy* can, const ss_sw_spectral* sw, const ss_lw_spectral* lw, ss_bc_out* bc,
+               ss_flux* const* fl, int nsw, int nlw, int c0, int c1, ChunkView& v) {
+  long l0 = -1, l1 = 0;
+  for (int j = c0; j < c1; ++j) {
+    if (can->nlay[j] <= 0) continue;
+    const long a = can->istartlay[j] - 1;
+    if (l0 < 0 || a < l0) l0 = a;
+    l1 = std::max(l1, a + can->nlay[j]);
+  }
+  if (l0 < 0) l0 = l1 = 0;
+  v.istartlay.resize(c1 - c0);
+  for (int j = c0; j < c1; ++j)
+    v.istartlay[j - c0] = can->nlay[j] > 0 ? (int32_t)(can->istartlay[j] - l0) : 1;
+  v.can = *can;
+  v.can.ncol = c1 - c0;
+  v.can.ntotlay = (int32_t)(l1 - l0);
+  v.can.nlay = can->nlay + c0;
+  v.can.istartlay = v.istartlay.data();
+  v.can.i_representation = can->i_representation + c0;
+  v.can.cos_sza = adv(can->cos_sza, c0);
+  v.can.ground_temperature = adv(can->ground_temperature, c0);
+#define LAYF(m) v.can.m = adv(can->m, l0)
+  LAYF(dz); LAYF(building_fraction); LAYF(veg_fraction); LAYF(building_scale); LAYF(veg_scale);
+  LAYF(veg_ext); LAYF(veg_fsd); LAYF(veg_contact_fraction); LAYF(roof_temperature);
+  LAYF(wall_temperature); LAYF(clear_air_temperature); LAYF(veg_temperature); LAYF(veg_air_temperature);
+#undef LAYF
+  if (sw) {
+    v.sw = *sw;
+    const long cl = (long)nsw * l0, cc = (long)nsw * c0;
+    v.sw.air_ext = adv(sw->air_ext, cl); v.sw.air_ssa = adv(sw->air_ssa, cl); v.sw.veg_ssa = adv(sw->veg_ssa, cl);
+    v.sw.ground_albedo = adv(sw->ground_albedo, cc); v.sw.ground_albedo_dir = adv(sw->ground_albedo_dir, cc);
+    v.sw.roof_albedo = adv(sw->roof_albedo, cl); v.sw.wall_albedo = adv(sw->wall_albedo, cl);
+    v.sw.roof_albedo_dir = adv(sw->roof_albedo_dir, cl); v.sw.wall_specular_frac = adv(sw->wall_specular_frac, cl);
+  }
+  if (lw) {
+    v.lw = *lw;
+    const long cl = (long)nlw * l0, cc = (long)nlw * c0;
+    v.lw.air_ext = adv(lw->air_ext, cl); v.lw.air_ssa = adv(lw->air_ssa, cl); v.lw.veg_ssa = adv(lw->veg_ssa, cl);
+    v.lw.clear_air_planck = adv(lw->clear_air_planck, cl); v.lw.veg_planck = adv(lw->veg_planck, cl);
+    v.lw.veg_air_planck = adv(lw->veg_air_planck, cl);
+    v.lw.ground_emissivity = adv(lw->ground_emissivity, cc); v.lw.ground_emission = adv(lw->ground_emission, cc);
+    v.lw.roof_emissivity = adv(lw->roof_emissivity, cl); v.lw.wall_emissivity = adv(lw->wall_emissivity, cl);
+    v.lw.roof_emission = adv(lw->roof_emission, cl); v.lw.wall_emission = adv(lw->wall_emission, cl);
+  }
+  v.bc.sw_albedo = adv(bc->sw_albedo, (long)nsw * c0);
+  v.bc.sw_albedo_dir = adv(bc->sw_albedo_dir, (long)nsw * c0);
+  v.bc.lw_emissivity = adv(bc->lw_emissivity, (long)nlw * c0);
+  v.bc.lw_emission = adv(bc->lw_emission, (long)nlw * c0);
+  for (int k = 0; k < 4; ++k) {
+    v.have_fl[k] = fl[k] != nullptr;
+    if (!fl[k]) continue;
+    v.fl[k] = *fl[k];
+    const int nspec = k < 2 ? nsw : nlw;
+    v.fl[k].ncol = c1 - c0;
+    v.fl[k].ntotlay = (int32_t)(l1 - l0);
+    double** m = &v.fl[k].ground_dn;
+    double* const* src = &fl[k]->ground_dn;
+    for (int F = 0; F < ss::F_NFIELDS; ++F) {
+      const int shape = ss::flux_field_shape(F);
+      const long off = shape == 0 ? (long)nspec * c0 : shape == 1 ? (long)nspec * l0 : shape == 2 ? c0 : l0;
+      m[F] = adv(src[F], off);
+    }
+  }
+}
+
+// columns per chunk: at least four chunks of a large call (so that copies and
+// kernels overlap), never tiny ones (launch and copy latencies), whole waves
+int chunk_columns_host(int ncols) {
+  const char* e = std::getenv("SPARTACUS_HOST_CHUNK");
+  if (e && std::atoi(e) > 0) return std::atoi(e);
+  int c = (ncols + 3) / 4;
+  c = std::max(c, 16384);
+  c = std::min(c, 262144);
+  return ((c + 63) / 64) * 64;
+}
+
+}  // namespace
+
 extern "C" {
 
 int ss_device_count(int32_t* count) {
@@ -298,16 +449,19 @@ int ss_device_count(int32_t* count) {
   return n > 0 ? SS_OK : SS_ERR_NO_DEVICE;
 }
 
+// Makes "device" current for plans created from now on.  Existing plans stay on
+// the device they were created on (each owns its streams); the host entry's cached
+// sub-plans are dropped when the device they live on is no longer the current one
+// at their next use.
 int ss_set_device(int32_t device) {
   int rc = device_ready();
   if (rc) return rc;
   if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return SS_ERR_HIP;
-  if (g_stream) { hipStreamDestroy(g_stream); g_stream = nullptr; }
   return SS_OK;
 }
 
 const char* ss_last_error(void) { return g_last_error.c_str(); }
-const char* ss_version(void) { return "spartacus_surface_hip 0.1 (gfx950)"; }
+const char* ss_version(void) { return "spartacus_surface_hip 0.2 (gfx950)"; }
 
 int ss_plan_create(ss_plan** plan, const ss_config* config, const ss_canopy* canopy,
                    const ss_sw_spectral* sw, const ss_lw_spectral* lw, int32_t istartcol,
@@ -317,17 +471,30 @@ int ss_plan_create(ss_plan** plan, const ss_config* config, const ss_canopy* can
   if (rc) return rc;
   return guarded([&]() {
     ss_plan* p = new ss_plan();
-    int r = p->impl.create(config, canopy, sw, lw, istartcol, iendcol, want_profiles);
+    int r;
+    try {
+      r = p->impl.create(config, canopy, sw, lw, istartcol, iendcol, want_profiles);
+    } catch (...) {
+      delete p;
+      throw;
+    }
     if (r) { g_last_error = p->impl.error; delete p; return r; }
     *plan = p;
     return (int)SS_OK;
   });
 }
 
+// Every plan entry makes the plan's own device current first.  A plan is not
+// re-entrant: calls on ONE plan must come from one thread at a time (different
+// plans are independent - they share no stream or event).
+#define SS_PLAN_ENTRY(plan) \
+  if (!(plan)) return SS_ERR_BAD_ARGUMENT
+
 int ss_plan_upload(ss_plan* plan, const ss_canopy* canopy, const ss_sw_spectral* sw,
                    const ss_lw_spectral* lw) {
   if (!plan || !canopy) return SS_ERR_BAD_ARGUMENT;
   return guarded([&]() {
+    plan->impl.be.activate();
     int r = plan->impl.upload(canopy, sw, lw);
     if (r) g_last_error = plan->impl.error;
     return r;
@@ -335,8 +502,9 @@ int ss_plan_upload(ss_plan* plan, const ss_canopy* canopy, const ss_sw_spectral*
 }
 
 int ss_plan_calc_simple_spectrum_lw(ss_plan* plan) {
-  if (!plan) return SS_ERR_BAD_ARGUMENT;
+  SS_PLAN_ENTRY(plan);
   return guarded([&]() {
+    plan->impl.be.activate();
     int r = plan->impl.simple_spectrum_lw();
     if (r) g_last_error = plan->impl.error;
     return r;
@@ -344,8 +512,9 @@ int ss_plan_calc_simple_spectrum_lw(ss_plan* plan) {
 }
 
 int ss_plan_solve(ss_plan* plan) {
-  if (!plan) return SS_ERR_BAD_ARGUMENT;
+  SS_PLAN_ENTRY(plan);
   return guarded([&]() {
+    plan->impl.be.activate();
     int r = plan->impl.solve();
     if (r) g_last_error = plan->impl.error;
     return r;
@@ -353,20 +522,24 @@ int ss_plan_solve(ss_plan* plan) {
 }
 
 int ss_plan_synchronize(ss_plan* plan) {
-  if (!plan) return SS_ERR_BAD_ARGUMENT;
-  return guarded([&]() { HipBackend::sync(); return (int)SS_OK; });
+  SS_PLAN_ENTRY(plan);
+  return guarded([&]() { plan->impl.be.activate(); plan->impl.be.sync(); return (int)SS_OK; });
 }
 
 int ss_plan_download(ss_plan* plan, ss_bc_out* bc_out, ss_flux* sw_norm_dir, ss_flux* sw_norm_diff,
                      ss_flux* lw_internal, ss_flux* lw_norm) {
-  if (!plan) return SS_ERR_BAD_ARGUMENT;
-  return guarded([&]() { return plan->impl.download(bc_out, sw_norm_dir, sw_norm_diff, lw_internal, lw_norm); });
+  SS_PLAN_ENTRY(plan);
+  return guarded([&]() {
+    plan->impl.be.activate();
+    return plan->impl.download(bc_out, sw_norm_dir, sw_norm_diff, lw_internal, lw_norm);
+  });
 }
 
 int ss_plan_last_kernel_ms(ss_plan* plan, const char* name, double* ms) {
   if (!plan || !name || !ms) return SS_ERR_BAD_ARGUMENT;
   return guarded([&]() {
-    HipBackend::sync();
+    plan->impl.be.activate();
+    plan->impl.be.sync();
     const std::string n(name);
     int count = 0;
     // "<family>" = summed device time of the family in the last solve,
@@ -395,13 +568,14 @@ int ss_plan_last_kernel_ms(ss_plan* plan, const char* name, double* ms) {
 
 int ss_plan_eigen_failures(ss_plan* plan, int64_t* count) {
   if (!plan || !count) return SS_ERR_BAD_ARGUMENT;
-  return guarded([&]() { *count = plan->impl.eigen_failures(); return (int)SS_OK; });
+  return guarded([&]() { plan->impl.be.activate(); *count = plan->impl.eigen_failures(); return (int)SS_OK; });
 }
 
 int ss_plan_scale_and_sum(ss_plan* plan, const double* top_flux_dn_sw, const double* top_flux_dn_direct_sw,
                           const double* top_flux_dn_lw) {
-  if (!plan) return SS_ERR_BAD_ARGUMENT;
+  SS_PLAN_ENTRY(plan);
   return guarded([&]() {
+    plan->impl.be.activate();
     int rc = plan->impl.scale_and_sum(top_flux_dn_sw, top_flux_dn_direct_sw, top_flux_dn_lw);
     if (rc) g_last_error = plan->impl.error;
     return rc;
@@ -409,13 +583,13 @@ int ss_plan_scale_and_sum(ss_plan* plan, const double* top_flux_dn_sw, const dou
 }
 
 int ss_plan_download_sums(ss_plan* plan, ss_flux* sw_flux, ss_flux* lw_flux) {
-  if (!plan) return SS_ERR_BAD_ARGUMENT;
-  return guarded([&]() { return plan->impl.download_sums(sw_flux, lw_flux); });
+  SS_PLAN_ENTRY(plan);
+  return guarded([&]() { plan->impl.be.activate(); return plan->impl.download_sums(sw_flux, lw_flux); });
 }
 
 int ss_plan_set_pipes(ss_plan* plan, int32_t npipes) {
   if (!plan || npipes < 1) return SS_ERR_BAD_ARGUMENT;
-  return guarded([&]() { return plan->impl.set_pipes(npipes); });
+  return guarded([&]() { plan->impl.be.activate(); return plan->impl.set_pipes(npipes); });
 }
 
 int ss_plan_device_ptr(ss_plan* plan, const char* name, void** ptr, int64_t* nelem) {
@@ -427,9 +601,27 @@ int ss_plan_device_ptr(ss_plan* plan, const char* name, void** ptr, int64_t* nel
   return SS_OK;
 }
 
+int ss_plan_device(ss_plan* plan, int32_t* device) {
+  if (!plan || !device) return SS_ERR_BAD_ARGUMENT;
+  *device = plan->impl.be.device;
+  return SS_OK;
+}
+
 int ss_plan_destroy(ss_plan* plan) {
   if (!plan) return SS_OK;
-  return guarded([&]() { HipBackend::sync(); delete plan; return (int)SS_OK; });
+  return guarded([&]() {
+    plan->impl.be.activate();
+    try { plan->impl.be.sync(); } catch (...) {}
+    delete plan;
+    return (int)SS_OK;
+  });
+}
+
+int ss_host_entry_plan_creations(int64_t* count) {
+  if (!count) return SS_ERR_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lock(g_device_mutex);
+  *count = g_host.creations;
+  return SS_OK;
 }
 
 int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, const ss_sw_spectral* sw,
@@ -439,40 +631,76 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
   if (!config || !canopy || !bc_out) return SS_ERR_BAD_ARGUMENT;
   int rc = device_ready();
   if (rc) return rc;
+  if (istartcol < 1 || iendcol > canopy->ncol || iendcol < istartcol - 1) {
+    g_last_error = "column range out of bounds";
+    return SS_ERR_BAD_ARGUMENT;
+  }
+  if (iendcol < istartcol) return SS_OK;
   // The reference is called concurrently on disjoint column ranges
-  // (spartacus_surface_driver.F90:206-233); one device, one stream: serialise.
+  // (spartacus_surface_driver.F90:206-233); one device: serialise.
   std::lock_guard<std::mutex> lock(g_device_mutex);
   return guarded([&]() {
-    const bool profiles = (sw_norm_dir && sw_norm_dir->flux_dn_layer_top)
-                          || (lw_internal && lw_internal->flux_dn_layer_top);
-    // A host model calls this entry once per time step with the same configuration and
-    // shapes: the plan (device mirrors, scratch: GiBs of hipMalloc) of the previous call is
-    // kept and only re-filled, unless SPARTACUS_NO_PLAN_CACHE is set.
-    static HipPlan* cached = nullptr;   // deliberately never destroyed at process exit (HIP may be gone)
-    static ss_config cached_cfg;
-    static int cached_dims[5] = {-1, -1, -1, -1, -1};
-    const int dims[5] = {canopy->ncol, canopy->ntotlay, istartcol, iendcol, profiles ? 1 : 0};
-    const bool reuse = cached && !std::getenv("SPARTACUS_NO_PLAN_CACHE")
-                       && std::memcmp(&cached_cfg, config, sizeof(ss_config)) == 0
-                       && std::memcmp(cached_dims, dims, sizeof(dims)) == 0;
-    int r;
-    if (reuse) {
-      r = cached->upload(canopy, sw, lw);
-    } else {
-      delete cached;
-      cached = new HipPlan;
-      cached->pipes_cap = 2;   // less scratch to allocate for what may be a one-shot call
-      r = cached->create(config, canopy, sw, lw, istartcol, iendcol, profiles ? 1 : 0);
-      cached_cfg = *config;
-      std::memcpy(cached_dims, dims, sizeof(dims));
+    const int profiles = ((sw_norm_dir && sw_norm_dir->flux_dn_layer_top)
+                          || (lw_internal && lw_internal->flux_dn_layer_top)) ? 1 : 0;
+    int device = 0;
+    HIP_CHECK_THROW(hipGetDevice(&device));
+    const bool nocache = std::getenv("SPARTACUS_NO_PLAN_CACHE") != nullptr;
+    if (g_host.slot[0] && (nocache || g_host.profiles != profiles || g_host.device != device
+                           || std::memcmp(&g_host.cfg, config, sizeof(ss_config)) != 0))
+      g_host.drop();
+    g_host.cfg = *config;
+    g_host.profiles = profiles;
+    g_host.device = device;
+
+    ss_flux* fl[4] = {config->do_sw ? sw_norm_dir : nullptr, config->do_sw ? sw_norm_diff : nullptr,
+                      config->do_lw ? lw_internal : nullptr, config->do_lw ? lw_norm : nullptr};
+    const bool always_seed = std::getenv("SPARTACUS_ALWAYS_SEED") != nullptr;
+    const int c_begin = istartcol - 1, c_end = iendcol;
+    const int chunk = chunk_columns_host(c_end - c_begin);
+    ChunkView views[2];
+    int pending = -1;          // slot whose results still have to come back
+    int r = SS_OK;
+    auto fail = [&](HipPlan* p, int code) {
+      if (p) g_last_error = p->error;
+      g_host.drop();
+      return code;
+    };
+    auto download = [&](int s) {
+      ChunkView& v = views[s];
+      return g_host.slot[s]->download(&v.bc, v.have_fl[0] ? &v.fl[0] : nullptr, v.have_fl[1] ? &v.fl[1] : nullptr,
+                                      v.have_fl[2] ? &v.fl[2] : nullptr, v.have_fl[3] ? &v.fl[3] : nullptr);
+    };
+    int k = 0;
+    for (int c0 = c_begin; c0 < c_end; c0 += chunk, ++k) {
+      const int c1 = std::min(c_end, c0 + chunk), s = k & 1;
+      ChunkView& v = views[s];
+      make_view(canopy, sw, lw, bc_out, fl, config->nsw, config->nlw, c0, c1, v);
+      HipPlan*& p = g_host.slot[s];
+      if (!p) {
+        p = new HipPlan;
+        p->pipes_cap = 2;   // less scratch to allocate for what may be a one-shot call
+        ++g_host.creations;
+        r = p->create(config, &v.can, sw ? &v.sw : nullptr, lw ? &v.lw : nullptr, 1, c1 - c0, profiles);
+      } else {
+        r = p->reset(&v.can, sw ? &v.sw : nullptr, lw ? &v.lw : nullptr, 1, c1 - c0);
+      }
+      if (r) return fail(p, r);
+      p->upload_outputs(&v.bc, v.have_fl[0] ? &v.fl[0] : nullptr, v.have_fl[1] ? &v.fl[1] : nullptr,
+                        v.have_fl[2] ? &v.fl[2] : nullptr, v.have_fl[3] ? &v.fl[3] : nullptr,
+                        always_seed ? (int)HipPlan::SEED_ALL : p->seed_needed());
+      r = p->solve();
+      if (r) return fail(p, r);
+      if (pending >= 0) {            // the other slot's chunk comes back while this one is solved
+        r = download(pending);
+        if (r) return fail(g_host.slot[pending], r);
+      }
+      pending = s;
     }
-    HipPlan& plan = *cached;
-    if (r) { g_last_error = plan.error; delete cached; cached = nullptr; return r; }
-    plan.upload_outputs(bc_out, sw_norm_dir, sw_norm_diff, lw_internal, lw_norm);
-    r = plan.solve();
-    if (r) { g_last_error = plan.error; delete cached; cached = nullptr; return r; }
-    r = plan.download(bc_out, sw_norm_dir, sw_norm_diff, lw_internal, lw_norm);
-    if (std::getenv("SPARTACUS_NO_PLAN_CACHE")) { delete cached; cached = nullptr; }
+    if (pending >= 0) {
+      r = download(pending);
+      if (r) return fail(g_host.slot[pending], r);
+    }
+    if (nocache) g_host.drop();
     return r;
   });
 }

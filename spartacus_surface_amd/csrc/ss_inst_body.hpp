@@ -1,9 +1,6 @@
 // ss_inst_body.hpp - body shared by the inst_*.hip units.  The including file
 // defines SS_INST_URBAN (true/false), SS_INST_NREG (1..3), SS_INST_LW (0/1)
 // and SS_INST_NAME (launcher symbol).
-#include <cstdio>
-#include <cstdlib>
-
 #include "ss_kernels.hpp"
 #include "ss_column_lw.hpp"
 #include "ss_column_sw.hpp"
@@ -70,21 +67,20 @@ __global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_DOWN)) k_
   else column_down_sw<U, R, NS>(L, cu, unit & 1);
 }
 
+#define SS_TRY(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
+
 template <int NS>
-void launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev) {
+int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev) {
   {
     // the plan sized the scratch with its own formula: it must match the records
     constexpr int N = SS_INST_NREG * NS, D = SS_INST_NREG;
     constexpr int lay_ne = SS_INST_LW ? LwRec<N>::NELEM : SwRec<N, D>::NELEM;
     constexpr int col_ne = SS_INST_LW ? LwColRec<N>::NELEM : SwColRec<N, D>::NELEM;
-    if (L.lay_nelem != lay_ne || L.col_nelem != col_ne) {
-      fprintf(stderr, "spartacus_surface_hip: scratch record size mismatch (%d/%d vs %d/%d)\n",
-              L.lay_nelem, L.col_nelem, lay_ne, col_ne);
-      abort();
-    }
+    if (L.lay_nelem != lay_ne || L.col_nelem != col_ne) return kLaunchBadRecord;
   }
+  if (L.ncu <= 0 || L.maxlay <= 0) return 0;
   const unsigned gx = (unsigned)((L.ncu + kBlock - 1) / kBlock);
-  if (ev) hipEventRecord(ev[0], stream);
+  if (ev) SS_TRY(hipEventRecord(ev[0], stream));
 #ifndef SS_LAYER_GRID_2D
   const dim3 glayer(((gx + 7) / 8) * 8 * (unsigned)L.maxlay);
 #else
@@ -92,34 +88,39 @@ void launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev) {
 #endif
   hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), glayer, dim3(kBlock), 0,
                      stream, L);
-  if (ev) hipEventRecord(ev[1], stream);
+  SS_TRY(hipGetLastError());
+  if (ev) SS_TRY(hipEventRecord(ev[1], stream));
   hipLaunchKernelGGL((k_column<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx), dim3(kBlock), 0,
                      stream, L);
-  if (ev) hipEventRecord(ev[2], stream);
+  SS_TRY(hipGetLastError());
+  if (ev) SS_TRY(hipEventRecord(ev[2], stream));
   {
     const unsigned gd = (unsigned)((2L * L.ncu + kBlock - 1) / kBlock);
     hipLaunchKernelGGL((k_down<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gd), dim3(kBlock), 0,
                        stream, L);
+    SS_TRY(hipGetLastError());
   }
-  if (ev) hipEventRecord(ev[3], stream);
+  if (ev) SS_TRY(hipEventRecord(ev[3], stream));
+  return 0;
 }
 
 }  // namespace
 
-void SS_INST_NAME(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev) {
+int SS_INST_NAME(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev) {
 #ifdef SS_ONLY_NS   // experiment builds: a single stream count per unit
-  if (ns == SS_ONLY_NS) launch_ns<SS_ONLY_NS>(L, stream, ev);
+  if (ns == SS_ONLY_NS) return launch_ns<SS_ONLY_NS>(L, stream, ev);
+  return (int)hipErrorInvalidValue;
 #else
   switch (ns) {
-    case 1: launch_ns<1>(L, stream, ev); break;
-    case 2: launch_ns<2>(L, stream, ev); break;
-    case 3: launch_ns<3>(L, stream, ev); break;
-    case 4: launch_ns<4>(L, stream, ev); break;
-    case 5: launch_ns<5>(L, stream, ev); break;
-    case 6: launch_ns<6>(L, stream, ev); break;
-    case 7: launch_ns<7>(L, stream, ev); break;
-    case 8: launch_ns<8>(L, stream, ev); break;
-    default: break;
+    case 1: return launch_ns<1>(L, stream, ev);
+    case 2: return launch_ns<2>(L, stream, ev);
+    case 3: return launch_ns<3>(L, stream, ev);
+    case 4: return launch_ns<4>(L, stream, ev);
+    case 5: return launch_ns<5>(L, stream, ev);
+    case 6: return launch_ns<6>(L, stream, ev);
+    case 7: return launch_ns<7>(L, stream, ev);
+    case 8: return launch_ns<8>(L, stream, ev);
+    default: return (int)hipErrorInvalidValue;
   }
 #endif
 }

@@ -16,10 +16,13 @@ constexpr int kBlock = 64;   // one wavefront per workgroup: no LDS sharing, no 
 // Implemented once per (urban, nreg) in inst_*.hip; ns selects the instance.
 // Launches the layer kernel over (ncu x maxlay) units, then the upward and the
 // downward column kernels over ncu units, on "stream"; ev[0..3] (optional) are
-// recorded before, between and after the three kernels.
-using SolverLauncher = void (*)(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev);
+// recorded before, between and after the three kernels.  Returns 0, the hipError_t
+// of the first failing launch / event record, or kLaunchBadRecord when the plan's
+// scratch record sizes disagree with the kernels' record types (nothing launched).
+constexpr int kLaunchBadRecord = -1;
+using SolverLauncher = int (*)(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev);
 
-#define SS_DECL_LAUNCHER(name) void name(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev)
+#define SS_DECL_LAUNCHER(name) int name(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev)
 SS_DECL_LAUNCHER(launch_sw_forest_r2);
 SS_DECL_LAUNCHER(launch_sw_forest_r3);
 SS_DECL_LAUNCHER(launch_sw_urban_r1);

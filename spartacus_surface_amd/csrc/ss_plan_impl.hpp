@@ -122,7 +122,7 @@ class Plan {
 
   // device mirrors by name
   std::map<std::string, void*> dev;
-  std::map<std::string, size_t> dev_elems;
+  std::map<std::string, size_t> dev_elems, dev_cap;
 
   std::vector<ColumnClass> sw_classes, lw_classes;
   std::vector<int32_t> flat_cols, night_cols, lwzero_urban_cols;
@@ -149,32 +149,35 @@ class Plan {
   static constexpr int kCounters = 32;
   unsigned long long* d_eigen_fail = nullptr;
 
+  Backend be;                    // device context of this plan: its own streams and events
   typename Backend::Timers timers;
   std::string error;
 
   ~Plan() { release(); }
 
   void release() {
-    for (auto& kv : dev) Backend::free(kv.second);
+    for (auto& kv : dev) be.free(kv.second);
     dev.clear();
     dev_elems.clear();
-    if (d_index) Backend::free(d_index);
+    dev_cap.clear();
+    if (d_index) be.free(d_index);
     free_packs(sw_classes);
     free_packs(lw_classes);
     for (int p = 0; p < kMaxPipes; ++p) {
-      if (d_lay[p]) Backend::free(d_lay[p]);
-      if (d_col[p]) Backend::free(d_col[p]);
+      if (d_lay[p]) be.free(d_lay[p]);
+      if (d_col[p]) be.free(d_col[p]);
       d_lay[p] = d_col[p] = nullptr;
     }
     lay_bytes = col_bytes = 0;
-    if (d_eigen_fail) Backend::free(d_eigen_fail);
+    if (d_eigen_fail) be.free(d_eigen_fail);
     d_index = nullptr; d_eigen_fail = nullptr;
     timers.release();
+    be.release();
   }
 
-  static void free_packs(std::vector<ColumnClass>& cls) {
+  void free_packs(std::vector<ColumnClass>& cls) {
     for (auto& c : cls) {
-      if (c.d_pack) Backend::free(c.d_pack);
+      if (c.d_pack) be.free(c.d_pack);
       c.d_pack = nullptr;
       c.pack_elems = 0;
     }
@@ -193,8 +196,8 @@ class Plan {
         const size_t tiles = (units + 63) / 64;
         const size_t need = tiles * 64 * (size_t)c.maxlay * (size_t)(lw ? kPackLw : kPackSw);
         if (!c.d_pack || c.pack_elems < need) {
-          if (c.d_pack) Backend::free(c.d_pack);
-          c.d_pack = static_cast<double*>(Backend::alloc(need * sizeof(double)));
+          if (c.d_pack) be.free(c.d_pack);
+          c.d_pack = static_cast<double*>(be.alloc(need * sizeof(double)));
           c.pack_elems = need;
         }
         PackLaunch P;
@@ -207,7 +210,7 @@ class Plan {
         P.urban = c.key.urban ? 1 : 0;
         P.nreg = c.key.nreg;
         P.pack = c.d_pack;
-        Backend::launch_pack(P, timers);
+        be.launch_pack(P, timers);
       }
     }
     packs_valid = true;
@@ -219,23 +222,27 @@ class Plan {
     auto it = dev.find(name);
     return it == dev.end() ? nullptr : static_cast<double*>(it->second);
   }
+  // Device arrays only grow: a plan that is re-targeted to another column set
+  // (reset(), the host entry's chunk loop and block calls) keeps its allocations;
+  // dev_elems is the logical size, dev_cap the allocated one (both in elements).
   void ensure(const std::string& name, size_t elems, size_t elsize = sizeof(double)) {
     auto it = dev.find(name);
-    if (it != dev.end() && dev_elems[name] == elems) return;
-    if (it != dev.end()) Backend::free(it->second);
-    void* p = Backend::alloc(elems * elsize);
-    Backend::memset(p, 0, elems * elsize);
+    if (it != dev.end() && dev_cap[name] >= elems) { dev_elems[name] = elems; return; }
+    if (it != dev.end()) be.free(it->second);
+    void* p = be.alloc(elems * elsize);
+    be.memset(p, 0, elems * elsize);
     dev[name] = p;
     dev_elems[name] = elems;
+    dev_cap[name] = elems;
   }
   void mirror(const std::string& name, const void* host, size_t elems, size_t elsize = sizeof(double)) {
     if (!host) {
       auto it = dev.find(name);
-      if (it != dev.end()) { Backend::free(it->second); dev.erase(it); dev_elems.erase(name); }
+      if (it != dev.end()) { be.free(it->second); dev.erase(it); dev_elems.erase(name); dev_cap.erase(name); }
       return;
     }
     ensure(name, elems, elsize);
-    Backend::h2d(dev[name], host, elems * elsize);
+    be.h2d(dev[name], host, elems * elsize);
   }
 
   // which canopy_flux members exist (allocate_canopy_flux, radsurf_canopy_flux.F90:96-163)
@@ -294,29 +301,35 @@ class Plan {
   int create(const ss_config* c, const ss_canopy* can, const ss_sw_spectral* sw,
              const ss_lw_spectral* lw, int i0, int i1, int profiles) {
     cfg = *c;
-    ncol = can->ncol;
-    ntotlay = can->ntotlay;
     nsw = c->nsw;
     nlw = c->nlw;
-    istartcol = i0;
-    iendcol = i1;
     want_profiles = profiles != 0;
-    if (i0 < 1 || i1 > ncol || i1 < i0 - 1) { error = "column range out of bounds"; return SS_ERR_BAD_ARGUMENT; }
-    if (cfg.do_sw && (!sw || sw->nspec != nsw)) { error = "sw spectral properties missing / nspec mismatch"; return SS_ERR_BAD_ARGUMENT; }
-    if (cfg.do_lw && (!lw || lw->nspec != nlw)) { error = "lw spectral properties missing / nspec mismatch"; return SS_ERR_BAD_ARGUMENT; }
     const char* mb = std::getenv("SPARTACUS_SCRATCH_MB");
     scratch_budget_bytes = (mb ? (size_t)std::atol(mb) : (size_t)4096) << 20;
     const char* np = std::getenv("SPARTACUS_PIPES");
     pipes_wanted = std::min(pipes_cap, np ? std::max(1, std::atoi(np)) : kDefaultPipes);
+    be.init();
+    d_eigen_fail = static_cast<unsigned long long*>(be.alloc(kCounters * sizeof(unsigned long long)));
+    be.memset(d_eigen_fail, 0, kCounters * sizeof(unsigned long long));
+    return reset(can, sw, lw, i0, i1);
+  }
 
+  // Point the plan at a column set (same configuration, any shape): output arrays
+  // for (ncol, ntotlay), inputs uploaded, columns of [i0, i1] classified.
+  int reset(const ss_canopy* can, const ss_sw_spectral* sw, const ss_lw_spectral* lw, int i0, int i1) {
+    ncol = can->ncol;
+    ntotlay = can->ntotlay;
+    istartcol = i0;
+    iendcol = i1;
+    if (i0 < 1 || i1 > ncol || i1 < i0 - 1) { error = "column range out of bounds"; return SS_ERR_BAD_ARGUMENT; }
+    if (cfg.do_sw && (!sw || sw->nspec != nsw)) { error = "sw spectral properties missing / nspec mismatch"; return SS_ERR_BAD_ARGUMENT; }
+    if (cfg.do_lw && (!lw || lw->nspec != nlw)) { error = "lw spectral properties missing / nspec mismatch"; return SS_ERR_BAD_ARGUMENT; }
     ensure("bc_out.sw_albedo", std::max<size_t>(1, (size_t)nsw * ncol));
     ensure("bc_out.sw_albedo_dir", std::max<size_t>(1, (size_t)nsw * ncol));
     ensure("bc_out.lw_emissivity", std::max<size_t>(1, (size_t)nlw * ncol));
     ensure("bc_out.lw_emission", std::max<size_t>(1, (size_t)nlw * ncol));
     if (cfg.do_sw) { alloc_flux("sw_norm_dir", nsw, true); alloc_flux("sw_norm_diff", nsw, true); }
     if (cfg.do_lw) { alloc_flux("lw_internal", nlw, false); alloc_flux("lw_norm", nlw, false); }
-    d_eigen_fail = static_cast<unsigned long long*>(Backend::alloc(kCounters * sizeof(unsigned long long)));
-    Backend::memset(d_eigen_fail, 0, kCounters * sizeof(unsigned long long));
     return upload(can, sw, lw);
   }
 
@@ -377,7 +390,9 @@ class Plan {
       mirror("lw.roof_emission", lw->roof_emission, ll);
       mirror("lw.wall_emission", lw->wall_emission, ll);
     }
-    return classify();
+    const int rc = classify();
+    be.sync();     // the caller may reuse (or free) its host arrays as soon as this returns
+    return rc;
   }
 
   int classify() {
@@ -449,7 +464,7 @@ class Plan {
         auto it = pool.find({lw, c.key});
         if (it != pool.end()) { c.d_pack = it->second.first; c.pack_elems = it->second.second; pool.erase(it); }
       }
-    for (auto& kv : pool) Backend::free(kv.second.first);
+    for (auto& kv : pool) be.free(kv.second.first);
 
     // one device index buffer: [sw classes][lw classes][flat][night][simple exp][simple inf]
     std::vector<int32_t> idx;
@@ -460,11 +475,11 @@ class Plan {
     for (int k = 0; k < 2; ++k) { simple_off[k] = idx.size(); idx.insert(idx.end(), simple_cols[k].begin(), simple_cols[k].end()); }
     if (idx.empty()) idx.push_back(0);
     if (!d_index || index_elems < idx.size()) {
-      if (d_index) Backend::free(d_index);
-      d_index = static_cast<int32_t*>(Backend::alloc(idx.size() * sizeof(int32_t)));
+      if (d_index) be.free(d_index);
+      d_index = static_cast<int32_t*>(be.alloc(idx.size() * sizeof(int32_t)));
       index_elems = idx.size();
     }
-    Backend::h2d(d_index, idx.data(), idx.size() * sizeof(int32_t));
+    be.h2d(d_index, idx.data(), idx.size() * sizeof(int32_t));
 
     // scratch sizing: the largest per-column need over all classes
     size_t need_lay = 0, need_col = 0;
@@ -486,16 +501,16 @@ class Plan {
     npipes = std::max(1, std::min<int>({kMaxPipes, pipes_wanted, (int)nlaunch}));
     if (need_lay > lay_bytes || need_col > col_bytes) {
       for (int p = 0; p < kMaxPipes; ++p) {
-        if (d_lay[p]) Backend::free(d_lay[p]);
-        if (d_col[p]) Backend::free(d_col[p]);
+        if (d_lay[p]) be.free(d_lay[p]);
+        if (d_col[p]) be.free(d_col[p]);
         d_lay[p] = d_col[p] = nullptr;
       }
       lay_bytes = std::max(lay_bytes, need_lay);
       col_bytes = std::max(col_bytes, need_col);
     }
     for (int p = 0; p < npipes; ++p) {
-      if (!d_lay[p]) d_lay[p] = static_cast<double*>(Backend::alloc(lay_bytes));
-      if (!d_col[p]) d_col[p] = static_cast<double*>(Backend::alloc(col_bytes));
+      if (!d_lay[p]) d_lay[p] = static_cast<double*>(be.alloc(lay_bytes));
+      if (!d_col[p]) d_col[p] = static_cast<double*>(be.alloc(col_bytes));
     }
     return SS_OK;
   }
@@ -505,8 +520,8 @@ class Plan {
     npipes = std::min(npipes, pipes_wanted);
     if (pipes_wanted > npipes && lay_bytes) {
       for (int p = npipes; p < pipes_wanted; ++p) {
-        if (!d_lay[p]) d_lay[p] = static_cast<double*>(Backend::alloc(lay_bytes));
-        if (!d_col[p]) d_col[p] = static_cast<double*>(Backend::alloc(col_bytes));
+        if (!d_lay[p]) d_lay[p] = static_cast<double*>(be.alloc(lay_bytes));
+        if (!d_col[p]) d_col[p] = static_cast<double*>(be.alloc(col_bytes));
       }
       npipes = pipes_wanted;
     }
@@ -662,60 +677,83 @@ class Plan {
   }
 
   // ---- one pass of the hot path ----
-  int solve() {
-    timers.begin_solve();
-    Backend::memset_async(d_eigen_fail, 0, kCounters * sizeof(unsigned long long));
-    if (!packs_valid) {      // first solve after an upload (or after the device spectrum changed the LW inputs)
-      int rc = pack_inputs();
-      if (rc) return rc;
-    }
+  // Everything that can fail on the host side is checked before the first launch,
+  // so that nothing returns between fork() and join(); a failing launch throws and
+  // the worker streams are still joined (the caller may solve again).
+  int validate_inputs() {
+    auto need = [&](const char* n) {
+      if (!darr(n)) { error = std::string("required input array not provided: ") + n; return false; }
+      return true;
+    };
     if (!flat_cols.empty()) {
-      if (cfg.do_sw && (!darr("sw.ground_albedo"))) { error = "sw.ground_albedo missing"; return SS_ERR_BAD_ARGUMENT; }
-      if (cfg.do_lw && (!darr("lw.ground_emissivity") || !darr("lw.ground_emission"))) { error = "lw ground arrays missing"; return SS_ERR_BAD_ARGUMENT; }
-      Backend::launch_flat(make_misc(flat_off, flat_cols.size()), timers);
+      if (cfg.do_sw && !need("sw.ground_albedo")) return SS_ERR_BAD_ARGUMENT;
+      if (cfg.do_lw && (!need("lw.ground_emissivity") || !need("lw.ground_emission"))) return SS_ERR_BAD_ARGUMENT;
     }
-    if (!night_cols.empty()) Backend::launch_night(make_misc(night_off, night_cols.size()), timers);
-    for (int k = 0; k < 2; ++k) {
-      if (simple_cols[k].empty()) continue;
-      auto need = [&](const char* n) {
-        if (!darr(n)) { error = std::string("required input array not provided: ") + n; return false; }
-        return true;
-      };
+    if (!simple_cols[0].empty() || !simple_cols[1].empty()) {
       bool ok = need("canopy.dz") && need("canopy.building_fraction") && need("canopy.building_scale");
       if (cfg.do_sw) ok = ok && need("canopy.cos_sza") && need("sw.ground_albedo") && need("sw.roof_albedo") && need("sw.wall_albedo")
                           && (!cfg.use_sw_direct_albedo || need("sw.ground_albedo_dir"));
       if (cfg.do_lw) ok = ok && need("lw.ground_emissivity") && need("lw.ground_emission") && need("lw.roof_emissivity")
                           && need("lw.roof_emission") && need("lw.wall_emissivity") && need("lw.wall_emission");
       if (!ok) return SS_ERR_BAD_ARGUMENT;
-      MiscLaunch M = make_misc(simple_off[k], simple_cols[k].size());
-      M.infinite_street = k;
-      Backend::launch_simple_urban(M, timers);
     }
-    Backend::fork(npipes);
-    int nlaunched = 0;
-    for (int lw = 0; lw < 2; ++lw) {
-      const auto& classes = lw ? lw_classes : sw_classes;
-      const int nspec = lw ? nlw : nsw;
-      for (const auto& c : classes) {
+    for (int lw = 0; lw < 2; ++lw)
+      for (const auto& c : (lw ? lw_classes : sw_classes)) {
         int rc = check_inputs(c.key, lw != 0);
         if (rc) return rc;
-        const size_t chunk = chunk_columns(c, lw != 0, nspec);
-        for (size_t first = 0; first < c.cols.size(); first += chunk) {
-          const size_t count = std::min(chunk, c.cols.size() - first);
-          const int chunk_maxlay = h_nlay[c.cols[first]];   // sorted descending
-          // Orders above SS_UNROLL_MAX keep their matrices in the hardware scratch
-          // (tens of KB per lane, GBs per queue): concurrent queues then fight over
-          // it (measured 5.5e5 -> 3.2e5 columns/s with four streams at n = 12), so
-          // those classes stay on the first stream.
-          const bool big_order = c.key.nreg * c.key.ns > SS_UNROLL_MAX;
-          const int pipe = big_order ? 0 : nlaunched++ % npipes;
-          Launch L = make_launch(c, lw != 0, first, count, chunk_maxlay, pipe);
-          Backend::launch_solver(c.key, lw != 0, L, timers, pipe);
+      }
+    return SS_OK;
+  }
+
+  int solve() {
+    int rc = validate_inputs();
+    if (rc) return rc;
+    be.begin_solve(timers);
+    bool forked = false;
+    try {
+      be.memset_async(d_eigen_fail, 0, kCounters * sizeof(unsigned long long));
+      if (!packs_valid) {      // first solve after an upload (or after the device spectrum changed the LW inputs)
+        rc = pack_inputs();
+        if (rc) { be.end_solve(timers); return rc; }
+      }
+      if (!flat_cols.empty()) be.launch_flat(make_misc(flat_off, flat_cols.size()), timers);
+      if (!night_cols.empty()) be.launch_night(make_misc(night_off, night_cols.size()), timers);
+      for (int k = 0; k < 2; ++k) {
+        if (simple_cols[k].empty()) continue;
+        MiscLaunch M = make_misc(simple_off[k], simple_cols[k].size());
+        M.infinite_street = k;
+        be.launch_simple_urban(M, timers);
+      }
+      be.fork(npipes);
+      forked = true;
+      int nlaunched = 0;
+      for (int lw = 0; lw < 2; ++lw) {
+        const auto& classes = lw ? lw_classes : sw_classes;
+        const int nspec = lw ? nlw : nsw;
+        for (const auto& c : classes) {
+          const size_t chunk = chunk_columns(c, lw != 0, nspec);
+          for (size_t first = 0; first < c.cols.size(); first += chunk) {
+            const size_t count = std::min(chunk, c.cols.size() - first);
+            const int chunk_maxlay = h_nlay[c.cols[first]];   // sorted descending
+            // Orders above SS_UNROLL_MAX keep their matrices in the hardware scratch
+            // (tens of KB per lane, GBs per queue): concurrent queues then fight over
+            // it (measured 5.5e5 -> 3.2e5 columns/s with four streams at n = 12), so
+            // those classes stay on the first stream.
+            const bool big_order = c.key.nreg * c.key.ns > SS_UNROLL_MAX;
+            const int pipe = big_order ? 0 : nlaunched++ % npipes;
+            Launch L = make_launch(c, lw != 0, first, count, chunk_maxlay, pipe);
+            be.launch_solver(c.key, lw != 0, L, timers, pipe);
+          }
         }
       }
+      be.join(npipes);
+      forked = false;
+      be.end_solve(timers);
+    } catch (...) {
+      if (forked) { try { be.join(npipes); } catch (...) {} }
+      try { be.end_solve(timers); } catch (...) {}
+      throw;
     }
-    Backend::join(npipes);
-    timers.end_solve();
     return SS_OK;
   }
 
@@ -748,7 +786,7 @@ class Plan {
     S.lay0 = h_istartlay[istartcol - 1] - 1;
     S.nlays = (h_istartlay[iendcol - 1] - 1 + h_nlay[iendcol - 1]) - S.lay0;
     if (S.nlays > 0 && (!S.clear_air_temperature || !S.clear_air_planck)) { error = "air temperature / planck arrays missing"; return SS_ERR_BAD_ARGUMENT; }
-    Backend::launch_spectrum(S, timers);
+    be.launch_spectrum(S, timers);
     packs_valid = false;     // emission / Planck arrays of the LW packs are stale now
     return SS_OK;
   }
@@ -759,28 +797,28 @@ class Plan {
     const double* d = darr(name);
     if (!d) return;
     const size_t off = (size_t)nspec * (istartcol - 1), n = (size_t)nspec * (iendcol - istartcol + 1);
-    Backend::d2h(host + off, d + off, n * sizeof(double));
+    be.d2h(host + off, d + off, n * sizeof(double));
   }
   void get_lays(const char* name, double* host, int nspec) {
     if (!host || lay_count <= 0) return;
     const double* d = darr(name);
     if (!d) return;
     const size_t off = (size_t)nspec * lay_first, n = (size_t)nspec * lay_count;
-    Backend::d2h(host + off, d + off, n * sizeof(double));
+    be.d2h(host + off, d + off, n * sizeof(double));
   }
   void put_cols(const char* name, const double* host, int nspec) {
     if (!host || iendcol < istartcol) return;
     double* d = darr(name);
     if (!d) return;
     const size_t off = (size_t)nspec * (istartcol - 1), n = (size_t)nspec * (iendcol - istartcol + 1);
-    Backend::h2d(d + off, host + off, n * sizeof(double));
+    be.h2d(d + off, host + off, n * sizeof(double));
   }
   void put_lays(const char* name, const double* host, int nspec) {
     if (!host || lay_count <= 0) return;
     double* d = darr(name);
     if (!d) return;
     const size_t off = (size_t)nspec * lay_first, n = (size_t)nspec * lay_count;
-    Backend::h2d(d + off, host + off, n * sizeof(double));
+    be.h2d(d + off, host + off, n * sizeof(double));
   }
   static double* const* flux_members(const ss_flux* f) { return &f->ground_dn; }
 
@@ -799,24 +837,37 @@ class Plan {
   }
 
   int download(ss_bc_out* bc, ss_flux* sw_dir, ss_flux* sw_diff, ss_flux* lw_int, ss_flux* lw_nrm) {
-    Backend::sync();
+    be.sync();
     if (bc) {
       if (cfg.do_sw) { get_cols("bc_out.sw_albedo", bc->sw_albedo, nsw); get_cols("bc_out.sw_albedo_dir", bc->sw_albedo_dir, nsw); }
       if (cfg.do_lw) { get_cols("bc_out.lw_emissivity", bc->lw_emissivity, nlw); get_cols("bc_out.lw_emission", bc->lw_emission, nlw); }
     }
     if (cfg.do_sw) { xfer_flux("sw_norm_dir", sw_dir, nsw, true); xfer_flux("sw_norm_diff", sw_diff, nsw, true); }
     if (cfg.do_lw) { xfer_flux("lw_internal", lw_int, nlw, true); xfer_flux("lw_norm", lw_nrm, nlw, true); }
+    be.sync();     // all copies were queued asynchronously: complete before the host reads
     return SS_OK;
   }
 
   // Seed the device outputs with the caller's current contents, so members the
   // reference leaves untouched (e.g. bc_out SW of night-time columns,
   // per-column members of flat tiles) round-trip unchanged.
-  int upload_outputs(const ss_bc_out* bc, ss_flux* sw_dir, ss_flux* sw_diff, ss_flux* lw_int, ss_flux* lw_nrm) {
+  // What has to be seeded for the classified column range: canopy columns in
+  // daylight write every element of every member (a test holds this against the
+  // seeded path with sentinel-filled outputs), night-time columns leave bc_out's
+  // shortwave members alone, flat and single-layer urban tiles leave most members.
+  enum { SEED_NONE = 0, SEED_BC_SW = 1, SEED_ALL = 2 };
+  int seed_needed() const {
+    if (!flat_cols.empty() || !simple_cols[0].empty() || !simple_cols[1].empty()) return SEED_ALL;
+    return night_cols.empty() ? SEED_NONE : SEED_BC_SW;
+  }
+  int upload_outputs(const ss_bc_out* bc, ss_flux* sw_dir, ss_flux* sw_diff, ss_flux* lw_int, ss_flux* lw_nrm,
+                     int mode = SEED_ALL) {
+    if (mode == SEED_NONE) return SS_OK;
     if (bc) {
       if (cfg.do_sw) { put_cols("bc_out.sw_albedo", bc->sw_albedo, nsw); put_cols("bc_out.sw_albedo_dir", bc->sw_albedo_dir, nsw); }
-      if (cfg.do_lw) { put_cols("bc_out.lw_emissivity", bc->lw_emissivity, nlw); put_cols("bc_out.lw_emission", bc->lw_emission, nlw); }
+      if (cfg.do_lw && mode == SEED_ALL) { put_cols("bc_out.lw_emissivity", bc->lw_emissivity, nlw); put_cols("bc_out.lw_emission", bc->lw_emission, nlw); }
     }
+    if (mode != SEED_ALL) return SS_OK;
     if (cfg.do_sw) { xfer_flux("sw_norm_dir", sw_dir, nsw, false); xfer_flux("sw_norm_diff", sw_diff, nsw, false); }
     if (cfg.do_lw) { xfer_flux("lw_internal", lw_int, nlw, false); xfer_flux("lw_norm", lw_nrm, nlw, false); }
     return SS_OK;
@@ -849,7 +900,7 @@ class Plan {
       S.lay0 = lay_first;
       S.nlays = lay_count;
       scale_sum_compact(S);
-      Backend::launch_scale_sum(S, timers);
+      be.launch_scale_sum(S, timers);
     };
     if (cfg.do_sw) {
       if (!top_sw || !top_sw_dir) { error = "top-of-canopy shortwave fluxes missing"; return SS_ERR_BAD_ARGUMENT; }
@@ -868,28 +919,31 @@ class Plan {
     return SS_OK;
   }
   int download_sums(ss_flux* sw_flux, ss_flux* lw_flux) {
-    Backend::sync();
+    be.sync();
     if (cfg.do_sw) xfer_flux("sw_flux", sw_flux, nsw, true);
     if (cfg.do_lw) xfer_flux("lw_flux", lw_flux, nlw, true);
+    be.sync();
     return SS_OK;
   }
 
   // emission / Planck arrays computed by simple_spectrum_lw go back to the host
   void download_spectrum(const ss_lw_spectral* lw) {
     if (!lw) return;
-    Backend::sync();
+    be.sync();
     get_cols("lw.ground_emission", lw->ground_emission, nlw);
     get_lays("lw.roof_emission", lw->roof_emission, nlw);
     get_lays("lw.wall_emission", lw->wall_emission, nlw);
     get_lays("lw.clear_air_planck", lw->clear_air_planck, nlw);
     get_lays("lw.veg_planck", lw->veg_planck, nlw);
     get_lays("lw.veg_air_planck", lw->veg_air_planck, nlw);
+    be.sync();
   }
 
   long long eigen_failures() {
-    Backend::sync();
+    be.sync();
     unsigned long long v[kCounters] = {0};
-    Backend::d2h(v, d_eigen_fail, sizeof(v));
+    be.d2h(v, d_eigen_fail, sizeof(v));
+    be.sync();
     if (std::getenv("SPARTACUS_PRINT_STAMPS")) {
       std::fprintf(stderr, "stamps:");
       for (int k = 1; k < kCounters; ++k) std::fprintf(stderr, " %llu", v[k]);

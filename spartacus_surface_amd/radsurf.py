@@ -38,7 +38,8 @@ EXPORTS = (
     "spartacus_radsurf_hip", "ss_plan_create", "ss_plan_upload",
     "ss_plan_calc_simple_spectrum_lw", "ss_plan_solve", "ss_plan_synchronize",
     "ss_plan_download", "ss_plan_last_kernel_ms", "ss_plan_eigen_failures", "ss_plan_set_pipes", "ss_plan_scale_and_sum", "ss_plan_download_sums",
-    "ss_plan_device_ptr", "ss_plan_destroy", "ss_device_count", "ss_set_device",
+    "ss_plan_device_ptr", "ss_plan_device", "ss_plan_destroy", "ss_host_entry_plan_creations",
+    "ss_device_count", "ss_set_device",
     "ss_last_error", "ss_version",
 )
 
@@ -84,6 +85,13 @@ def device_count():
 
 def set_device(index):
     _check(load_library().ss_set_device(C.c_int32(index)))
+
+
+def host_entry_plan_creations():
+    """Device plans the host entry has built so far in this process."""
+    n = C.c_int64(0)
+    _check(load_library().ss_host_entry_plan_creations(C.byref(n)))
+    return n.value
 
 
 def _flux_ptr(f):
@@ -185,6 +193,11 @@ class Plan:
         n = C.c_int64(0)
         _check(self._lib.ss_plan_device_ptr(self._h, name.encode(), C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def device(self):
+        d = C.c_int32(-1)
+        _check(self._lib.ss_plan_device(self._h, C.byref(d)))
+        return d.value
 
     def close(self):
         if self._h:

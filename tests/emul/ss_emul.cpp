@@ -17,10 +17,12 @@ namespace {
 
 struct EmulBackend {
   struct Timers {
-    void begin_solve() {}
-    void end_solve() {}
     void release() {}
   };
+  static void init() {}
+  static void release() {}
+  static void begin_solve(Timers&) {}
+  static void end_solve(Timers&) {}
   static void* alloc(size_t n) { return std::malloc(n ? n : 1); }
   static void free(void* p) { std::free(p); }
   static void memset(void* p, int v, size_t n) { std::memset(p, v, n); }

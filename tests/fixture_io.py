@@ -47,11 +47,21 @@ def pack_case(case, outputs=None, want_profiles=True):
     return d
 
 
-def save_case(path, case, outputs, want_profiles=True, noise=None):
+def save_case(path, case, outputs, want_profiles=True, noise=None, truth=None, noise_arr=None):
+    """noise: {var: scalar} = the reference's own error per variable (max over elements);
+    truth / noise_arr: for the variables whose bar is widened by that noise
+    (NOISE_FACTOR x noise > PARITY_TOL) the binary128 result and the per-element
+    noise, so that the bar can be applied element by element and against exact
+    arithmetic (parity_report)."""
     d = pack_case(case, outputs, want_profiles)
     if noise is not None:
         for k, v in noise.items():
             d["noise." + k] = np.float64(v)
+            if NOISE_FACTOR * v > PARITY_TOL:
+                if truth is not None and k in truth:
+                    d["truth." + k] = np.asarray(truth[k], dtype=np.float64)
+                if noise_arr is not None and k in noise_arr:
+                    d["noisearr." + k] = np.asarray(noise_arr[k], dtype=np.float32)
     np.savez_compressed(path, **d)
 
 
@@ -67,7 +77,7 @@ def load_case(path):
     cp = CanopyProperties()
     sw = SwSpectralProperties(nspec=cfg.nsw)
     lw = LwSpectralProperties(nspec=cfg.nlw)
-    expected, drv, noise = {}, {}, {}
+    expected, drv, noise, truth, noise_arr = {}, {}, {}, {}, {}
     for k in z.files:
         if k.startswith("canopy."):
             setattr(cp, k[7:], np.array(z[k]))
@@ -81,13 +91,18 @@ def load_case(path):
             expected[k[4:]] = np.array(z[k])
         elif k.startswith("noise."):
             noise[k[6:]] = float(z[k])
+        elif k.startswith("truth."):
+            truth[k[6:]] = np.array(z[k])
+        elif k.startswith("noisearr."):
+            noise_arr[k[9:]] = np.array(z[k], dtype=np.float64)
     cp.ncol = int(cp.nlay.size)
     cp.ntotlay = int(cp.nlay.sum())
     sw.ncol = lw.ncol = cp.ncol
     sw.ntotlay = lw.ntotlay = cp.ntotlay
     cp.normalise(); sw.normalise(); lw.normalise()
     case = dict(config=cfg, canopy=cp, sw=sw, lw=lw, do_simple_spectrum=do_simple,
-                want_profiles=want_profiles, ref_noise=noise, **drv)
+                want_profiles=want_profiles, ref_noise=noise, ref_truth=truth, ref_noise_arr=noise_arr,
+                **drv)
     return case, expected
 
 
@@ -118,48 +133,105 @@ def _object_scales(expected):
     return scales
 
 
-def rel_errors(got, expected, floor=1.0e-3, zero_floor=1.0e-9):
-    """Per-variable error metric:
-        max |got - ref| / max(|ref|, floor * max|ref_v|, zero_floor * S_obj)
+def rel_error_arrays(got, expected, floor=1.0e-3, zero_floor=1.0e-9):
+    """Per-variable, per-element error metric:
+        |got - ref| / max(|ref|, floor * max|ref_v|, zero_floor * S_obj)
     where S_obj is the flux scale of the object the variable belongs to; the
     last term only matters for variables that are physically zero (e.g. the
     reflected flux of a non-scattering canopy), which otherwise would be
-    compared relative to their own rounding noise.  NaN/inf anywhere -> inf."""
+    compared relative to their own rounding noise.  A variable with NaN/inf
+    anywhere maps to None."""
     out = {}
     scales = _object_scales(expected)
     for k, ref in expected.items():
-        if ref.size == 0:
+        if ref.size == 0 or k not in got:
             continue
         g = got[k]
         obj = k.split(".")[0]
         s_obj = scales.get(k if obj == "bc_out" else obj, 0.0)
         if not (np.all(np.isfinite(g)) and np.all(np.isfinite(ref))):
-            out[k] = float("inf")
+            out[k] = None
             continue
         scale = float(np.max(np.abs(ref)))
         den = np.maximum(np.maximum(np.abs(ref), floor * scale), max(zero_floor * s_obj, 1.0e-300))
-        out[k] = float(np.max(np.abs(g - ref) / den))
+        out[k] = np.abs(g - ref) / den
     return out
+
+
+def rel_errors(got, expected, floor=1.0e-3, zero_floor=1.0e-9):
+    """max over the elements of :func:`rel_error_arrays`; NaN/inf anywhere -> inf."""
+    return {k: (float("inf") if e is None else float(np.max(e)))
+            for k, e in rel_error_arrays(got, expected, floor, zero_floor).items()}
 
 
 # Parity bar (BASELINE.json north_star): fluxes within 1e-5 relative of the
 # reference.  Where the reference's own fp64 result is farther than that from
 # the exact-arithmetic value of its algorithm (degenerate eigen-spectra of
-# identical regions, SURVEY.md section 7; measured per variable with the
-# binary128 build of the oracle and stored in the fixture as ref_noise), no
-# fp64 implementation can match it more closely than that noise: the bar for
-# such a variable is NOISE_FACTOR x the reference's own error.
+# identical regions, cancellation in thin layers; measured with the binary128
+# build of the oracle plus the sensitivity to last-bit input perturbations and
+# stored in the fixture), no fp64 implementation can match it more closely than
+# that noise.  For such a variable
+#   (1) the bar is applied ELEMENT BY ELEMENT: |got - ref| <= max(1e-5, 4 x the
+#       reference's own noise at that element) - one ill-conditioned element does
+#       not loosen the bar of the others;
+#   (2) the result must be as good an fp64 evaluation as the reference's: its
+#       distance from exact arithmetic (binary128) is at most
+#       max(1e-5, 4 x the reference's distance from exact arithmetic).
+# (2) is what keeps a bar of 0.2 or 50 from being vacuous.
 PARITY_TOL = 1.0e-5
 NOISE_FACTOR = 4.0
 
 
-def parity_violations(got, expected, ref_noise, tol=PARITY_TOL, noise_factor=NOISE_FACTOR):
-    """[(name, error, allowed)] for every variable outside the parity bar."""
+def parity_report(got, expected, ref_noise, truth=None, noise_arr=None, tol=PARITY_TOL,
+                  noise_factor=NOISE_FACTOR):
+    """{var: dict(err, bar, ref_noise, ok[, worst_excess, gpu_vs_truth, ref_vs_truth])}.
+
+    err            max relative |got - ref|
+    bar            max(tol, noise_factor x ref_noise) - the per-variable bar
+    worst_excess   max over elements of err_elem / allowed_elem (per-element bar; <= 1 passes)
+    gpu_vs_truth / ref_vs_truth   max relative distance from the binary128 result
+    """
+    truth = truth or {}
+    noise_arr = noise_arr or {}
+    rep = {}
+    errs = rel_error_arrays(got, expected)
+    for k, e in errs.items():
+        n = float(ref_noise.get(k, 0.0))
+        bar = max(tol, noise_factor * n)
+        r = {"err": float("inf") if e is None else float(np.max(e)), "bar": bar, "ref_noise": n}
+        ok = e is not None and r["err"] <= bar
+        if ok and bar > tol:
+            if k in noise_arr and noise_arr[k].shape == e.shape:
+                allowed = np.maximum(tol, noise_factor * noise_arr[k] * (1.0 + 1.0e-6) + 1.0e-30)
+                r["worst_excess"] = float(np.max(e / allowed))
+                ok = ok and r["worst_excess"] <= 1.0
+            if k in truth:
+                t = {k: truth[k]}
+                # both distances in the metric of the reference (same denominators)
+                eg = rel_error_arrays({k: got[k] - truth[k] + expected[k]}, {k: expected[k]})[k]
+                er = rel_error_arrays({k: truth[k]}, {k: expected[k]})[k]
+                if eg is not None and er is not None:
+                    r["gpu_vs_truth"] = float(np.max(eg))
+                    r["ref_vs_truth"] = float(np.max(er))
+                    ok = ok and r["gpu_vs_truth"] <= max(tol, noise_factor * r["ref_vs_truth"])
+        r["ok"] = bool(ok)
+        rep[k] = r
+    return rep
+
+
+def parity_violations(got, expected, ref_noise, tol=PARITY_TOL, noise_factor=NOISE_FACTOR, truth=None,
+                      noise_arr=None, collect=None, label=None):
+    """[(name, error, allowed)] for every variable outside the parity bar.
+    collect: optional dict that receives the full report under "label" (the GPU
+    test-suite dumps it to gpurun_out/parity_*.json for the record)."""
+    rep = parity_report(got, expected, ref_noise, truth, noise_arr, tol, noise_factor)
+    if collect is not None and label is not None:
+        collect[label] = rep
     bad = []
-    for k, e in rel_errors(got, expected).items():
-        allowed = max(tol, noise_factor * ref_noise.get(k, 0.0))
-        if not e <= allowed:
-            bad.append((k, e, allowed))
+    for k, r in rep.items():
+        if not r["ok"]:
+            bad.append((k, r["err"], r["bar"], {x: r[x] for x in ("worst_excess", "gpu_vs_truth", "ref_vs_truth")
+                                              if x in r}))
     return bad
 
 

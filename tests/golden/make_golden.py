@@ -10,12 +10,16 @@ compiled reference in oracle/_ref):
 For every run of the reference's own `make test` that exercises the hot path
 (tests/cases.py) this freezes the solver inputs and the reference's fp64
 outputs (all members of bc_out and of the four canopy_flux objects, before
-scale/sum) into one compressed .npz.  The rami5 set is thinned to keep the
-repository small: every scene with diffuse illumination (real soil) and its
-first direct-beam angle with real and black soil.
+scale/sum) into one compressed .npz, together with the reference's own rounding
+noise per variable and - for the variables whose parity bar that noise widens -
+the binary128 result and the per-element noise (tests/fixture_io.parity_report).
+All illuminations of test/rami5/Makefile:37-45 are kept (36 runs, ~6 MB).
 """
+import copy
 import os
 import sys
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -28,7 +32,7 @@ def main():
     out_dir = os.path.dirname(os.path.abspath(__file__))
     checker.build()
     total = 0
-    todo = cases.extra_cases() if "--extra" in sys.argv else cases.all_cases(rami5="subset")
+    todo = cases.extra_cases() if "--extra" in sys.argv else cases.all_cases(rami5="all")
     only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
     for name, build in todo.items():
         if only and not any(o in name for o in only):
@@ -43,22 +47,29 @@ def main():
                                       want_profiles=True, quad=True, nthreads=8,
                                       do_simple_spectrum=case["do_simple_spectrum"])
         ref_flat = fixture_io.flatten_outputs(outputs)
-        noise = fixture_io.rel_errors(ref_flat, fixture_io.flatten_outputs(truth))
+        truth_flat = fixture_io.flatten_outputs(truth)
+        # per element, in the metric of the parity bar (denominators from the reference's values)
+        noise_arr = {k: v for k, v in fixture_io.rel_error_arrays(truth_flat, ref_flat).items() if v is not None}
         # ... and its sensitivity to a last-bit change of the inputs (layer
         # thickness scaled by 1 +- few ulp), which also exposes configurations
         # where the algorithm itself is singular (test_noscat) and the
         # binary128 value is meaningless
-        import copy
         for eps in (1.0e-15, -1.0e-15, 3.0e-15, -4.0e-15, 1.0e-13, -1.0e-13):
             cp2 = copy.deepcopy(case["canopy"])
             cp2.dz = cp2.dz * (1.0 + eps)
             pert, _ = checker.run_oracle(case["config"], cp2, case["sw"], case["lw"],
                                          want_profiles=True, nthreads=8,
                                          do_simple_spectrum=case["do_simple_spectrum"])
-            for k, v in fixture_io.rel_errors(fixture_io.flatten_outputs(pert), ref_flat).items():
-                noise[k] = max(noise.get(k, 0.0), v)
+            for k, v in fixture_io.rel_error_arrays(fixture_io.flatten_outputs(pert), ref_flat).items():
+                if v is not None and k in noise_arr:
+                    noise_arr[k] = np.maximum(noise_arr[k], v)
+        noise = {k: float(np.max(v)) for k, v in noise_arr.items()}
+        for k, v in ref_flat.items():
+            if v.size and k not in noise:
+                noise[k] = float("inf")
         path = os.path.join(out_dir, name.replace("/", "__") + ".npz")
-        fixture_io.save_case(path, case, outputs, want_profiles=True, noise=noise)
+        fixture_io.save_case(path, case, outputs, want_profiles=True, noise=noise, truth=truth_flat,
+                             noise_arr=noise_arr)
         total += os.path.getsize(path)
         print("%-50s %7.1f KB" % (name, os.path.getsize(path) / 1024.0))
     print("total %.2f MB" % (total / 1048576.0))

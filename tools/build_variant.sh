@@ -1,9 +1,10 @@
 #!/bin/bash
-# usage: build_variant.sh NAME "FLAGS"  -> /root/repo/spartacus_surface_amd/lib/variants/libss_NAME.so
+# usage: build_variant.sh NAME "FLAGS"  -> <repo>/spartacus_surface_amd/lib/variants/libss_NAME.so
 set -e
 NAME=$1; FLAGS=$2; NSV=${3:-2}
-cd /root/repo/spartacus_surface_amd/csrc
-OD=/tmp/exp/$NAME; mkdir -p $OD ../lib/variants
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+cd "$ROOT/spartacus_surface_amd/csrc"
+OD="${TMPDIR:-/tmp}/ss_variants/$NAME"; mkdir -p $OD ../lib/variants
 for u in inst_sw_urban_r3 inst_lw_urban_r3; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-cuda-compat -DSS_ONLY_NS=$NSV $FLAGS -c $u.hip -o $OD/$u.o &
 done

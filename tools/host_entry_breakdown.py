@@ -1,5 +1,5 @@
-import time, sys
-sys.path.insert(0, "/root/repo")
+import os, time, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 from spartacus_surface_amd import radsurf, workloads, types
 from oracle import checker
