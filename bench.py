@@ -1,20 +1,28 @@
 #!/usr/bin/env python3
 """bench.py - canopy columns/s of the SPARTACUS-Surface SW+LW column solver on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c3ns4|c4] [--scaling weak|strong]
 
 A "step" is one pass of the hot path (radsurf: layer kernels + column kernels,
 SW and LW) over one batch of synthetic columns that is already resident in HBM.
-Workload at every N: BASELINE.json configs[2] = C3 of SURVEY.md section 8(d)
+Default workload at every N: BASELINE.json configs[2] = C3 of SURVEY.md section 8(d)
 (test/urban vegetated-urban column on 10 layers, 3 regions x 2 streams, 1 SW +
-1 LW band, 10^6 jittered columns per GPU, seed 12345).  With N > 1 every rank
-owns its own 10^6-column shard (weak scaling, no data-path collective); the only
-exchange is the final gather of the top-of-canopy boundary conditions
-(bc_out: albedos, emissivity, emission) over RCCL.
+1 LW band, 10^6 jittered columns per GPU, seed 12345 + rank), weak scaling.
+`--workload c4 --scaling strong` is BASELINE.json configs[3] as stated: 10^6 mixed
+forest / urban columns with 14 SW + 16 LW bands IN TOTAL, sharded over the N GPUs.
+
+With N > 1 every rank owns a contiguous column shard (one process per GPU, no
+data-path collective).  The exchange step of the path is the FINAL gather of the
+results: after the last step bc_out and every allocated member of the four flux
+objects go from the plans' device memory to rank 0 over RCCL, device to device
+(spartacus_surface_amd.distributed.DeviceGather), inside the timed region; the
+four bc_out arrays (what a host atmosphere model needs every step) are gathered
+after every step.
 
 Rank 0 prints one JSON line with the throughput, the roofline of the dominant
-kernel (HIP-event timing on the library's own stream) and the reference's CPU
-path timed on the host cores of the same box.
+kernel (HIP-event timing on the stream each kernel runs on, taken from steps with
+strictly serial kernels so that the durations do not overlap) and the reference's
+CPU path timed on the host cores of the same box.
 """
 import argparse
 import json
@@ -96,11 +104,13 @@ def cpu_baseline(workload, ncol_sample):
     return base, parity_of_sample(case, ref_out, kind)
 
 
-def parity_of_sample(case, ref_out, kind):
+def parity_of_sample(case, ref_out, kind, ntruth=2048):
     """The second half of BASELINE.json's metric: max relative |flux difference| between
     the GPU path and the CPU checker on the sample the CPU baseline just computed (every
-    member of bc_out and of the four flux objects; error metric of tests/fixture_io.py)."""
-    from spartacus_surface_amd import radsurf
+    member of bc_out and of the four flux objects; error metric of tests/fixture_io.py),
+    and - on the first ntruth columns plus the column of every worst element - the
+    distance of BOTH from exact arithmetic (the same algorithm in binary128)."""
+    from spartacus_surface_amd import radsurf, workloads
     from oracle import checker
     from tests import fixture_io
     cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
@@ -109,20 +119,38 @@ def parity_of_sample(case, ref_out, kind):
     out = checker.alloc_outputs(cfg, cp, False)
     plan.download(out["bc_out"], out["sw_norm_dir"], out["sw_norm_diff"], out["lw_internal"], out["lw_norm"])
     plan.close()
-    errs = fixture_io.rel_errors(fixture_io.flatten_outputs(out), fixture_io.flatten_outputs(ref_out))
+    g, r = fixture_io.flatten_outputs(out), fixture_io.flatten_outputs(ref_out)
+    errs = fixture_io.rel_errors(g, r)
     worst = max(errs, key=errs.get)
     over = {k: v for k, v in errs.items() if v > 1.0e-5}
     res = {"max_rel_error": errs[worst], "where": worst, "against": kind, "columns": int(cp.ncol),
            "variables": len(errs), "above_1e-5": over,
-           "note": "relative to max(|ref|, 1e-3 max|ref| of the variable); for the variables above 1e-5 "
-                   "(if any) 'worst_elements' gives the column of the worst element and the CPU "
-                   "restatement's own distance from exact arithmetic (same algorithm in binary128) at "
-                   "that element: the parity bar of the test-suite is max(1e-5, 4 x reference noise) "
-                   "(DESIGN.md section 2)"}
+           "note": "relative to max(|ref|, 1e-3 max|ref| of the variable).  'vs_exact' compares GPU and "
+                   "reference with the binary128 evaluation of the same algorithm on a subset of the sample: "
+                   "where the reference itself is farther than 1e-5 from exact arithmetic no fp64 result can "
+                   "match it to 1e-5; the parity bar of the test-suite is tests/fixture_io.py (DESIGN.md section 2)"}
+    # distance from exact arithmetic: first ntruth columns of the sample
+    nt = int(min(ntruth, cp.ncol))
+    head = workloads.head_columns(case, nt)
+    a = (head["config"], head["canopy"], head["sw"], head["lw"])
+    t = fixture_io.flatten_outputs(checker.run_oracle(*a, want_profiles=False, quad=True,
+                                                      nthreads=min(16, os.cpu_count() or 1))[0])
+    nl = int(head["canopy"].ntotlay)
+    cut = lambda x: x[:nt] if x.shape[0] == cp.ncol else x[:nl]   # noqa: E731
+    gh, rh = {k: cut(v) for k, v in g.items()}, {k: cut(v) for k, v in r.items()}
+    e_gpu = fixture_io.rel_errors({k: gh[k] - t[k] + rh[k] for k in rh}, rh)
+    e_ref = fixture_io.rel_errors(t, rh)
+    e_gr = fixture_io.rel_errors(gh, rh)
+    wk = max(e_gpu, key=e_gpu.get)
+    res["vs_exact"] = {"columns": nt, "gpu_vs_exact_max": e_gpu[wk], "gpu_vs_exact_where": wk,
+                       "reference_vs_exact_max": max(e_ref.values()),
+                       "reference_vs_exact_where": max(e_ref, key=e_ref.get),
+                       "gpu_vs_reference_max": max(e_gr.values()),
+                       "variables_where_gpu_is_farther_from_exact_than_reference_and_1e-5":
+                           sorted(k for k in e_gpu if e_gpu[k] > max(1.0e-5, e_ref[k]))}
     if over:
-        # where is the worst element of each such variable, and how far is the
-        # CPU restatement itself from exact arithmetic in that very column?
-        g, r = fixture_io.flatten_outputs(out), fixture_io.flatten_outputs(ref_out)
+        # where is the worst element of each such variable, and how far are GPU and
+        # reference from exact arithmetic in that very column?
         detail = {}
         for k in over:
             den = np.maximum(np.abs(r[k]), 1.0e-3 * float(np.max(np.abs(r[k]))))
@@ -130,49 +158,76 @@ def parity_of_sample(case, ref_out, kind):
             idx = np.unravel_index(int(np.argmax(e)), e.shape)
             per_col = r[k].shape[0] == cp.ncol
             col = int(idx[0]) if per_col else int(np.searchsorted(cp.istartlay - 1, idx[0], side="right") - 1)
-            f64 = fixture_io.flatten_outputs(checker.run_oracle(cfg, cp, sw, lw, want_profiles=False,
-                                                                istartcol=col + 1, iendcol=col + 1)[0])
             f128 = fixture_io.flatten_outputs(checker.run_oracle(cfg, cp, sw, lw, want_profiles=False,
                                                                  istartcol=col + 1, iendcol=col + 1, quad=True)[0])
             detail[k] = {"column": col, "error": float(e[idx]),
-                         "reference_noise_there": float(abs(f64[k][idx] - f128[k][idx]) / den[idx])}
+                         "reference_noise_there": float(abs(r[k][idx] - f128[k][idx]) / den[idx]),
+                         "gpu_vs_exact_there": float(abs(g[k][idx] - f128[k][idx]) / den[idx])}
         res["worst_elements"] = detail
     return res
 
 
-def measured_traffic(family, cols_per_launch, workload="c3"):
-    """HBM bytes per launch of a kernel family from the committed PMC summary
-    (profiles/traffic.json, written by tools/pmc_to_profile.py from separate
-    rocprofv3 --pmc passes; FETCH_SIZE doubled per MI355X_MICROARCH.md)."""
+def pmc_summary(workload):
+    """The committed PMC summary of the headline workload (profiles/traffic.json, written by
+    tools/pmc_to_profile.py from separate rocprofv3 --pmc passes; FETCH_SIZE doubled per
+    MI355X_MICROARCH.md): bytes moved between L2 and the fabric and executed fp64 flops,
+    per column and kernel family."""
     if workload != "c3":
-        return None, None
+        return None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
-        return t["bytes_per_column"][family] * cols_per_launch, t.get("source")
+        t["bytes_per_column"], t["fp64_flops_per_column_executed"]     # noqa: B018
+        return t
     except (OSError, KeyError, ValueError):
-        return None, None
+        return None
 
 
-def fp64_figure(flops_model, ncol, ms_per_step, workload):
+def fp64_figure(flops_model, ncol, ms_per_step, pmc):
     """fp64 rate of the whole step (wall time of the timed region: with several
     streams the per-kernel durations overlap and must not be added up): in the
     operation count of the reference's algorithm (SURVEY 8d model) and, where the
     PMC summary is committed, in the flops the kernels actually execute."""
     ach = flops_model * ncol / (ms_per_step * 1e-3) / 1e12
-    out = {"achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
-           "flops_per_column_model": flops_model,
+    out = {"bound": "fp64-valu", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": ach / FP64_PEAK_TFLOPS, "flops_per_column_model": flops_model,
            "note": "model flops of the reference's operation sequence per column x columns / step time"}
-    if workload == "c3":
-        try:
-            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                ex = sum(json.load(f)["fp64_flops_per_column_executed"].values())
-            out["flops_per_column_executed"] = ex
-            out["achieved_executed"] = ex * ncol / (ms_per_step * 1e-3) / 1e12
-            out["frac_executed"] = out["achieved_executed"] / FP64_PEAK_TFLOPS
-        except (OSError, KeyError, ValueError):
-            pass
+    if pmc:
+        ex = sum(pmc["fp64_flops_per_column_executed"].values())
+        out["flops_per_column_executed"] = ex
+        out["achieved_executed"] = ex * ncol / (ms_per_step * 1e-3) / 1e12
+        out["frac_executed"] = out["achieved_executed"] / FP64_PEAK_TFLOPS
     return out
+
+
+def roofline_block(fam_ms, fam_n, nsteps, columns, bpc, pmc, evidence, ms_per_step, fpc):
+    """Roofline of the dominant kernel family from NON-overlapping durations: avg launch
+    duration from HIP events of steps whose kernels ran strictly one after the other."""
+    dom = max(fam_ms, key=lambda k: fam_ms[k])
+    avg_ms = fam_ms[dom] / max(1, fam_n[dom])
+    cols_per_launch = columns * nsteps / max(1, fam_n[dom])
+    achieved = bpc * cols_per_launch / (avg_ms * 1e-3) / 1e9
+    rl = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "evidence": evidence,
+          "algorithmic_bytes_per_column": bpc, "avg_launch_ms": avg_ms,
+          "columns_per_launch": cols_per_launch, "launches_per_step": fam_n[dom] / nsteps,
+          "serial_ms_per_step_all_kernels": sum(fam_ms.values()) / nsteps,
+          "note": "intensity ~%.0f flop/B by algorithmic bytes: the path cannot be HBM-bound on them; what "
+                  "binds it is fp64 issue ('fp64', 'fp64_frac_of_dominant_kernel') and the traffic of its own "
+                  "intermediate records ('hbm_traffic_frac')" % (fpc / bpc)}
+    if pmc:
+        tb = pmc["bytes_per_column"]
+        rl["traffic"] = tb.get(dom, 0.0) * cols_per_launch
+        rl["traffic_source"] = pmc.get("source")
+        rl["traffic_bytes_per_column_total"] = sum(tb.values())
+        rl["traffic_over_algorithmic"] = sum(tb.values()) / bpc
+        # all bytes the kernels of a step move through L2 <-> fabric / the wall time of a step / HBM peak
+        rl["hbm_traffic_frac"] = sum(tb.values()) * columns / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+        rl["hbm_traffic_frac_of_dominant_kernel"] = rl["traffic"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        fl = pmc["fp64_flops_per_column_executed"].get(dom)
+        if fl:
+            rl["fp64_frac_of_dominant_kernel"] = fl * cols_per_launch / (avg_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
+    return rl
 
 
 def scale_sum_rate(plan, case, ncol):
@@ -226,28 +281,23 @@ def host_entry_rate(ncol):
     return {"value": ncol / best, "unit": "columns/s", "sample": "%d columns, host buffers in/out" % ncol}
 
 
-class _DevArray:
-    """CUDA-array-interface view of a device array owned by the plan."""
-
-    def __init__(self, ptr, nelem):
-        self.__cuda_array_interface__ = {"shape": (nelem,), "typestr": "<f8",
-                                         "data": (ptr, False), "version": 2}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--columns", type=int, default=1_000_000, help="columns per GPU")
+    ap.add_argument("--columns", type=int, default=1_000_000,
+                    help="columns per GPU (weak scaling) or in total (strong scaling)")
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3ns4", "c4"],
                     help="c3 (default) is the headline configuration; the others are extra lines")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --columns per GPU; strong: --columns in total, sharded over the GPUs "
+                         "(BASELINE.json configs[3] is --workload c4 --scaling strong)")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="timed region only: no serial-kernel steps, no CPU baseline, no PCIe sample "
-                         "(what the rocprofv3 kernel-trace run uses, so that its per-kernel averages "
-                         "are those of the timed region)")
+                         "(what the rocprofv3 runs use, so that the profiler sees the timed region only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -272,33 +322,40 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     cdev = "cpu" if rehearsal else "cuda"
 
-    from spartacus_surface_amd import radsurf, workloads
+    from spartacus_surface_amd import distributed, radsurf, workloads
     radsurf.load_library()
     radsurf.set_device(local_rank)
 
-    case = make_case(args.workload, args.columns, 12345 + rank)
+    # this rank's columns: its own seeded batch (weak), or its share of the total (strong;
+    # the columns are i.i.d. draws, so a shard is generated directly instead of cutting it
+    # out of 10^6 x 66 KB of host arrays on every rank)
+    if args.scaling == "strong":
+        r = distributed.shard_ranges(np.full(args.columns, 1), world)[rank]
+        my_cols = max(0, r[1] - r[0] + 1)
+    else:
+        my_cols = args.columns
+    total_cols_per_step = args.columns if args.scaling == "strong" else args.columns * world
+    case = make_case(args.workload, my_cols, 12345 + rank)
     cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
     plan = radsurf.Plan(cfg, cp, sw, lw, want_profiles=False)   # inputs now resident in HBM
 
-    gather = None
+    gather_bc = gather_all = None
     if world > 1:
-        names = ("bc_out.sw_albedo", "bc_out.sw_albedo_dir", "bc_out.lw_emissivity", "bc_out.lw_emission")
-        views = [torch.as_tensor(_DevArray(*plan.device_ptr(n)), device="cuda") for n in names]
-        outs = [torch.empty(world * v.numel(), dtype=torch.float64, device=cdev) for v in views]
-
-        def gather():
-            plan.synchronize()                      # results of the library's streams are complete
-            for v, o in zip(views, outs):
-                dist.all_gather_into_tensor(o, v.cpu() if rehearsal else v)
-            torch.cuda.synchronize()                # ... and gathered before the next solve overwrites them
+        bc_names = ["bc_out." + n for n in ("sw_albedo", "sw_albedo_dir", "lw_emissivity", "lw_emission")]
+        gather_bc = distributed.DeviceGather(plan, dist, cp.ncol, cp.ntotlay, names=bc_names, stage_host=rehearsal)
+        gather_all = distributed.DeviceGather(plan, dist, cp.ncol, cp.ntotlay, stage_host=rehearsal)
 
     def step():
         plan.solve()
-        if gather:
-            gather()
+        if gather_bc:
+            plan.synchronize()                      # results of the plan's streams are complete
+            gather_bc()                             # ... and on rank 0 before the next solve overwrites them
 
     for _ in range(args.warmup):
         step()
+    if gather_all and args.warmup > 0:
+        plan.synchronize()
+        gather_all()                                # RCCL channels of the big gather set up outside the timed region
     plan.synchronize()
     torch.cuda.synchronize()
     if world > 1:
@@ -308,10 +365,16 @@ def main():
     fam_n = dict.fromkeys(fam_ms, 0)
     for _ in range(args.steps):
         step()
-        # HIP-event times of this step's launches (the query waits for the stream)
+        # HIP-event times of this step's launches (the query waits for the plan's stream)
         for k in fam_ms:
             fam_ms[k] += plan.kernel_ms(k)
             fam_n[k] += int(plan.kernel_ms(k + ".launches"))
+    final_gather_ms = None
+    if gather_all:
+        plan.synchronize()
+        tg = time.perf_counter()
+        gather_all()                                # the exchange step of the path: every flux member to rank 0
+        final_gather_ms = 1e3 * (time.perf_counter() - tg)
     plan.synchronize()
     torch.cuda.synchronize()
     if world > 1:
@@ -324,10 +387,11 @@ def main():
     nfail = plan.eigen_failures()
 
     # two extra, untimed steps with strictly serial kernels (one stream): per-kernel
-    # durations without the chunk overlap of the timed region
+    # durations without the chunk overlap of the timed region - the evidence the roofline
+    # block is computed from
     pipes = int(os.environ.get("SPARTACUS_PIPES", "4"))
-    serial_ms = None
-    if pipes > 1 and not args.no_extras:
+    serial_ms = serial_n = None
+    if pipes > 1 and not args.no_extras and rank == 0:
         plan.set_pipes(1)
         serial_ms = {k: 0.0 for k in fam_ms}
         serial_n = dict.fromkeys(fam_ms, 0)
@@ -339,60 +403,64 @@ def main():
         plan.synchronize()
 
     if rank == 0:
-        total_cols = args.columns * world * args.steps
-        value = total_cols / elapsed
+        value = total_cols_per_step * args.steps / elapsed
+        ms_per_step = 1e3 * elapsed / args.steps
         bytes_in, bytes_out = workloads.algorithmic_bytes_per_column(case)
         bpc = bytes_in + bytes_out
-        dom = max(fam_ms, key=lambda k: fam_ms[k])
-        avg_ms = fam_ms[dom] / max(1, fam_n[dom])
-        cols_per_launch = args.columns * args.steps / max(1, fam_n[dom])
-        achieved = bpc * cols_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic(dom, cols_per_launch, args.workload)
         fpc = flops_per_column(case)
+        pmc = pmc_summary(args.workload)
+        # per-GPU step time for the per-kernel figures (what one GPU's kernels see)
+        if serial_ms is not None:
+            roofline = roofline_block(serial_ms, serial_n, 2, my_cols, bpc, pmc,
+                                      "2 untimed steps on one stream (kernels strictly serial)", ms_per_step, fpc)
+        elif pipes == 1:
+            roofline = roofline_block(fam_ms, fam_n, args.steps, my_cols, bpc, pmc,
+                                      "timed region, one stream (kernels strictly serial)", ms_per_step, fpc)
+        else:
+            roofline = {"bound": "hbm", "kernel": None, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": None, "traffic": None,
+                        "note": "not computed: with %d streams the event-bracketed kernel durations of the timed "
+                                "region overlap (they add up to more than the step), and --no-extras skipped the "
+                                "serial steps; run without --no-extras or with SPARTACUS_PIPES=1" % pipes}
         line = {
             "metric": "canopy columns/s (SW+LW)", "value": value, "unit": "columns/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s, %d columns per GPU, seed 12345"
-                                   % (WORKLOAD_NAMES[args.workload], args.columns),
-                       "columns_per_gpu": args.columns,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s, %d columns %s, seed 12345 + rank"
+                                   % (WORKLOAD_NAMES[args.workload], args.columns,
+                                      "per GPU" if args.scaling == "weak" else "in total, sharded over the GPUs"),
+                       "columns_per_gpu": my_cols, "columns_per_step": total_cols_per_step,
                        "layers": float(cp.ntotlay) / max(1, cp.ncol), "nsw": cfg.nsw,
                        "nlw": cfg.nlw, "parallelism": "columns sharded, %d GPU(s)" % world},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_column": bpc, "avg_launch_ms": avg_ms,
-                         "launches_per_step": fam_n[dom] / args.steps,
-                         "note": "intensity ~%.0f flop/B: the path is fp64-VALU bound, "
-                                 "see 'fp64'" % (fpc / bpc)},
-            "fp64": fp64_figure(fpc, args.columns, 1e3 * elapsed / args.steps, args.workload),
+            "roofline": roofline,
+            "fp64": fp64_figure(fpc, my_cols, ms_per_step, pmc),
             "streams": pipes,
-            "kernel_ms_per_step": {k: v / args.steps for k, v in fam_ms.items()},
+            "kernel_spans_ms_per_step": {k: v / args.steps for k, v in fam_ms.items()},
+            "kernel_spans_note": "event-bracketed spans of the timed region; with streams > 1 they overlap in "
+                                 "time and are NOT durations to add up or to divide bytes by",
             "eigen_failures": nfail,
         }
         if serial_ms is not None:
-            sd = max(serial_ms, key=lambda k: serial_ms[k])
-            s_avg = serial_ms[sd] / max(1, serial_n[sd])
-            s_cols = args.columns * 2 / max(1, serial_n[sd])
-            s_ach = bpc * s_cols / (s_avg * 1e-3) / 1e9
-            s_tot = sum(serial_ms.values()) / 2
             line["kernel_ms_per_step_serial"] = {k: v / 2 for k, v in serial_ms.items()}
-            line["roofline_serial"] = {
-                "note": "same kernels on one stream (2 extra untimed steps): no overlap between chunks",
-                "bound": "hbm", "kernel": sd, "achieved": s_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": s_ach / HBM_PEAK_GBS, "avg_launch_ms": s_avg,
-                "traffic": measured_traffic(sd, s_cols, args.workload)[0],
-                "fp64_tflops": fpc * args.columns / (s_tot * 1e-3) / 1e12,
-                "fp64_frac": fpc * args.columns / (s_tot * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
+        if world > 1:
+            line["final_gather"] = {"ms": final_gather_ms, "bytes_per_rank": gather_all.bytes_per_rank,
+                                    "arrays": len(gather_all.names),
+                                    "GB/s_into_rank0": (world - 1) * gather_all.bytes_per_rank
+                                    / (final_gather_ms * 1e-3) / 1e9 if final_gather_ms else None,
+                                    "note": "bc_out + every allocated member of the four flux objects, device to "
+                                            "device over RCCL, once after the last step, inside the timed region; "
+                                            "bc_out alone after every step"}
         if world == 1 and not args.no_extras and case.get("top_flux_dn_sw") is not None:
-            line["scale_sum"] = scale_sum_rate(plan, case, args.columns)
+            line["scale_sum"] = scale_sum_rate(plan, case, my_cols)
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
-            line["cpu_baseline"], line["parity"] = cpu_baseline(args.workload, min(args.cpu_sample, args.columns))
-            line["pcie_inclusive"] = host_entry_rate(min(args.columns, 200_000))
+            line["cpu_baseline"], line["parity"] = cpu_baseline(args.workload, min(args.cpu_sample, my_cols))
+            line["vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
+            line["pcie_inclusive"] = host_entry_rate(min(my_cols, 200_000))
         print(json.dumps(line), flush=True)
     plan.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

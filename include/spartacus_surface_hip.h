@@ -313,6 +313,45 @@ int ss_plan_destroy(ss_plan *plan);
  * so far in this process (diagnostic: block-wise calls must not rebuild them). */
 int ss_host_entry_plan_creations(int64_t *count);
 
+/* --------------------------------------------------------------------------
+ * Kernel-level entry points: the layer-matrix units of the hot path on their
+ * own, with the argument lists of radtool's routines (stacks of nmat independent
+ * problems, HOST arrays in Fortran layout x(nmat, i, j) -> x[m + nmat*(i + n*j)]).
+ * They launch the same device bodies the solver kernels inline, one lane per
+ * problem.  Instantiated orders: (ndiff, ndir) in {(1,1) (2,1) (2,2) (3,3) (4,2)
+ * (6,3) (8,2) (12,3)} for the shortwave, 1 2 3 4 6 8 12 for the longwave and
+ * 1 2 3 4 5 6 8 12 for the eigen-decomposition; others return SS_ERR_UNSUPPORTED.
+ * Any output pointer may be NULL.
+ * -------------------------------------------------------------------------- */
+/* calc_matrices_sw_eig (radtool/radtool_calc_matrices_sw_eig.F90:30-298, with
+ * schur_invert_sw radtool/radtool_schur.F90:32-53 for the three int_* outputs).
+ * dscale0 (nmat, ndir) / dscale (nmat, ndiff): optional scaling vectors d with
+ * diag(d)^-1 Gamma diag(d) symmetric (the solver passes sqrt(region fraction) and
+ * sqrt(fraction * weight * mu)); with them orders 3..6 take the symmetric
+ * eigen-route, NULL = the reference's general route.  sym_route (nmat, optional)
+ * receives 1 where the symmetric route was taken.  mu0 is accepted for the
+ * reference's signature and unused, as in the reference (:377, :384). */
+int ss_calc_matrices_sw_eig(int32_t nmat, int32_t ndiff, int32_t ndir, double dz, double mu0,
+                            const double *gamma0, const double *gamma1, const double *gamma2,
+                            const double *gamma3, const double *dscale0, const double *dscale,
+                            double *reflectance, double *transmittance, double *s_up, double *s_dn,
+                            double *trans_dir, double *int_dir, double *int_diff,
+                            double *int_dir_diff, int32_t *sym_route);
+/* calc_matrices_lw_eig (radtool/radtool_calc_matrices_lw_eig.F90:32-230). */
+int ss_calc_matrices_lw_eig(int32_t nmat, int32_t norder, double dz, const double *gamma1,
+                            const double *gamma2, const double *emiss_rate, const double *dscale,
+                            double *reflectance, double *transmittance, double *source,
+                            double *int_flux, double *int_flux_source);
+/* eigen_decomposition_real (radtool/radtool_eigen_decomposition.F90:51-828; note
+ * its argument order norder, nmat).  force_general_loops != 0 runs the run-time
+ * loop form for every order instead of the register-resident form of orders 3..6
+ * (same arithmetic, must agree bit for bit).  ierr (nmat, optional): 0 or the
+ * index at which the QR iteration gave up (:498-510). */
+int ss_eigen_decomposition_real(int32_t norder, int32_t nmat, const double *amat,
+                                double *eigenvalue, double *eigenvector,
+                                int32_t force_general_loops, int32_t *ierr);
+const char *ss_units_last_error(void);
+
 /* Library / device information. */
 int ss_device_count(int32_t *count);
 /* hipSetDevice for plans created from now on and for the host entry; existing

@@ -103,3 +103,167 @@ def gather_flat_outputs(local, ranges, layer_ranges, ncol, ntotlay, dist, device
 
 _PER_COLUMN = {n for n, k in abi.FLUX_FIELDS if k in ("sc", "c")} | set(abi.BC_FIELDS)
 _PER_LAYER = {n for n, k in abi.FLUX_FIELDS if k in ("sl", "l")}
+
+
+# --------------------------------------------------------------------------
+# Final gather from device memory (the contract of the
+# reference's output objects: radsurf/radsurf_canopy_flux.F90:27-91,
+# radsurf/radsurf_boundary_conds_out.F90:24-39; what the driver writes out
+# after its solver loop: driver/spartacus_surface_driver.F90:206-234, 250-265)
+# --------------------------------------------------------------------------
+OUTPUT_OBJECTS = ("sw_norm_dir", "sw_norm_diff", "lw_internal", "lw_norm")
+
+
+class _DevArray:
+    """CUDA-array-interface view of a device array owned by a plan."""
+
+    def __init__(self, ptr, nelem):
+        self.__cuda_array_interface__ = {"shape": (int(nelem),), "typestr": "<f8",
+                                         "data": (int(ptr), False), "version": 2}
+
+
+def output_names(plan):
+    """Names of every output array the plan holds on the device: the four members of
+    bc_out and every ALLOCATED member of the four flux objects, in a fixed order."""
+    names = ["bc_out." + n for n in abi.BC_FIELDS]
+    for obj in OUTPUT_OBJECTS:
+        for n, _ in abi.FLUX_FIELDS:
+            names.append("%s.%s" % (obj, n))
+    have = []
+    for n in names:
+        try:
+            plan.device_ptr(n)
+        except Exception:       # member not allocated in this configuration
+            continue
+        have.append(n)
+    return have
+
+
+class HostArrays:
+    """Stand-in for a plan whose "device" arrays are host arrays: lets the CPU test-suite
+    (gloo, no GPU) drive DeviceGather's packing, the single gather and the unpacking.
+    arrays: {name: ndarray with rows first}."""
+
+    def __init__(self, arrays):
+        self.arrays = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in arrays.items()}
+
+    def device_ptr(self, name):
+        a = self.arrays[name]           # KeyError = "member not allocated"
+        return a.ctypes.data, int(a.size)
+
+    def host_array(self, name):
+        return self.arrays[name]
+
+    def device(self):
+        return -1
+
+
+def _per_column(name):
+    return name.startswith("bc_out.") or name.split(".")[-1] in _PER_COLUMN
+
+
+class DeviceGather:
+    """Gather of bc_out and the four flux objects of every rank's plan to rank
+    ``root``, from device memory to device memory: every rank packs its output
+    arrays (views of ``ss_plan_device_ptr``, no host staging) into one send buffer
+    padded to the largest shard, ONE ``gather`` (grouped send/recv in RCCL: each
+    peer pushes its shard over its own xGMI link into the root) moves it, and the
+    root strips the padding into full-size device arrays.  There is no reduction
+    and no all-to-all: the ring bound of an all-reduce does not apply.
+
+    names=None gathers everything; a subset (e.g. the four bc_out arrays that a
+    host atmosphere model needs every step) gets its own instance.
+
+    stage_host=True is for rehearsals of the N > 1 path where no RCCL is possible
+    (several ranks on one GPU over ``gloo``): buffers go through host memory.
+    """
+
+    def __init__(self, plan, dist, ncol_local, ntotlay_local, names=None, root=0, stage_host=False):
+        import torch
+        self.torch = torch
+        self.dist = dist
+        self.plan = plan
+        self.root = root
+        self.stage_host = stage_host
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.names = list(names) if names is not None else output_names(plan)
+        on_host = hasattr(plan, "host_array")            # HostArrays stand-in (CPU tests)
+        stage_host = self.stage_host = stage_host or on_host
+        dev = torch.device("cpu") if on_host else torch.device("cuda", plan.device())
+        self.device = dev
+        cdev = torch.device("cpu") if stage_host else dev
+        self.views, widths = [], []
+        for n in self.names:
+            ptr, nelem = plan.device_ptr(n)
+            rows = ncol_local if _per_column(n) else ntotlay_local
+            # logical size: rows x width (an array of an empty shard still has one element allocated)
+            width = (nelem // rows) if rows > 0 else 0
+            widths.append(width)
+            used = rows * width
+            if on_host:
+                self.views.append(torch.from_numpy(plan.host_array(n).reshape(-1))[:used])
+            else:
+                self.views.append(torch.as_tensor(_DevArray(ptr, max(1, nelem)), device=dev)[:used])
+        # every rank learns every rank's (ncol, ntotlay) and the member widths (identical on ranks with data)
+        meta = torch.tensor([ncol_local, ntotlay_local] + widths, dtype=torch.int64, device=cdev)
+        allmeta = [torch.zeros_like(meta) for _ in range(self.world)]
+        dist.all_gather(allmeta, meta)
+        allmeta = [m.cpu().numpy() for m in allmeta]
+        self.ncols = [int(m[0]) for m in allmeta]
+        self.nlays = [int(m[1]) for m in allmeta]
+        self.widths = [int(max(m[2 + i] for m in allmeta)) for i in range(len(self.names))]
+        # layout of the packed buffer: per member a slot of (largest shard rows) x width
+        maxc, maxl = max(self.ncols), max(self.nlays)
+        self.slot = [(maxc if _per_column(n) else maxl) * w for n, w in zip(self.names, self.widths)]
+        self.offset = np.concatenate(([0], np.cumsum(self.slot))).astype(np.int64)
+        total = int(self.offset[-1])
+        self.send = torch.zeros(max(1, total), dtype=torch.float64, device=cdev)
+        self.recv = None
+        self.full = None
+        if self.rank == root:
+            self.recv = [torch.empty_like(self.send) for _ in range(self.world)]
+            self.full = {}
+            tc, tl = sum(self.ncols), sum(self.nlays)
+            for n, w in zip(self.names, self.widths):
+                rows = tc if _per_column(n) else tl
+                self.full[n] = torch.zeros(rows * w, dtype=torch.float64, device=cdev)
+        self.bytes_per_rank = 8 * total
+
+    def __call__(self):
+        """Pack, gather, unpack.  The plan's streams must be idle (plan.synchronize())."""
+        torch, dist = self.torch, self.dist
+        for i, v in enumerate(self.views):
+            if v.numel():
+                o = int(self.offset[i])
+                self.send[o:o + v.numel()].copy_(v)
+        if not self.stage_host:
+            torch.cuda.synchronize(self.device)
+        dist.gather(self.send, self.recv if self.rank == self.root else None, dst=self.root)
+        if self.rank != self.root:
+            return None
+        c0 = l0 = 0
+        for r in range(self.world):
+            for i, n in enumerate(self.names):
+                rows = self.ncols[r] if _per_column(n) else self.nlays[r]
+                cnt = rows * self.widths[i]
+                if cnt == 0:
+                    continue
+                start = (c0 if _per_column(n) else l0) * self.widths[i]
+                o = int(self.offset[i])
+                self.full[n][start:start + cnt].copy_(self.recv[r][o:o + cnt])
+            c0 += self.ncols[r]
+            l0 += self.nlays[r]
+        if not self.stage_host:
+            torch.cuda.synchronize(self.device)
+        return self.full
+
+    def to_host(self):
+        """{name: ndarray (rows, width)} of the assembled arrays (root only)."""
+        out = {}
+        kinds = dict(abi.FLUX_FIELDS)
+        for n, w in zip(self.names, self.widths):
+            a = self.full[n].cpu().numpy()
+            two_d = n.startswith("bc_out.") or kinds[n.split(".")[-1]] in ("sc", "sl")
+            out[n] = a.reshape(-1, max(1, w)) if two_d else a
+        return out

@@ -41,6 +41,8 @@ EXPORTS = (
     "ss_plan_device_ptr", "ss_plan_device", "ss_plan_destroy", "ss_host_entry_plan_creations",
     "ss_device_count", "ss_set_device",
     "ss_last_error", "ss_version",
+    "ss_calc_matrices_sw_eig", "ss_calc_matrices_lw_eig", "ss_eigen_decomposition_real",
+    "ss_units_last_error",
 )
 
 
@@ -64,8 +66,9 @@ def load_library():
         _lib = C.CDLL(_LIB_PATH)
         _lib.ss_last_error.restype = C.c_char_p
         _lib.ss_version.restype = C.c_char_p
+        _lib.ss_units_last_error.restype = C.c_char_p
         for name in EXPORTS:
-            if name not in ("ss_last_error", "ss_version"):
+            if name not in ("ss_last_error", "ss_version", "ss_units_last_error"):
                 getattr(_lib, name).restype = C.c_int
     return _lib
 
@@ -114,6 +117,73 @@ def radsurf(config, canopy_props, sw_spectral_props, lw_spectral_props, bc_out,
     args = [C.byref(k) for k in keep] + [C.c_int32(istartcol), C.c_int32(iendcol)]
     args += [C.byref(f) if f is not None else None for f in fl]
     _check(lib.spartacus_radsurf_hip(*args))
+
+
+# ---- kernel-level entry points (radtool's routines on the device) ----
+def _fstack(a):
+    return np.asfortranarray(a, dtype=np.float64)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _check_units(rc):
+    if rc != 0:
+        msg = load_library().ss_units_last_error()
+        raise SpartacusHipError("%s (%d): %s" % (STATUS.get(rc, "error"), rc, msg.decode() if msg else ""))
+
+
+def calc_matrices_sw_eig(dz, mu0, gamma0, gamma1, gamma2, gamma3, dscale0=None, dscale=None):
+    """radtool's calc_matrices_sw_eig on the device: stacks (nmat, n, n) etc. in, dict of
+    stacks out (plus 'sym_route': 1 where the symmetric eigen-route was taken)."""
+    lib = load_library()
+    g0, g1, g2, g3 = _fstack(gamma0), _fstack(gamma1), _fstack(gamma2), _fstack(gamma3)
+    nmat, nd, _ = g1.shape
+    nr = g0.shape[1]
+    d0 = _fstack(dscale0) if dscale0 is not None else None
+    d1 = _fstack(dscale) if dscale is not None else None
+    z = lambda *s: np.zeros(s, order="F")  # noqa: E731
+    o = dict(reflectance=z(nmat, nd, nd), transmittance=z(nmat, nd, nd), s_up=z(nmat, nd, nr),
+             s_dn=z(nmat, nd, nr), trans_dir=z(nmat, nr, nr), int_dir=z(nmat, nr, nr),
+             int_diff=z(nmat, nd, nd), int_dir_diff=z(nmat, nd, nr))
+    route = np.zeros(nmat, dtype=np.int32)
+    _check_units(lib.ss_calc_matrices_sw_eig(
+        C.c_int32(nmat), C.c_int32(nd), C.c_int32(nr), C.c_double(dz), C.c_double(mu0),
+        _fp(g0), _fp(g1), _fp(g2), _fp(g3), _fp(d0), _fp(d1),
+        *[_fp(o[k]) for k in ("reflectance", "transmittance", "s_up", "s_dn", "trans_dir", "int_dir",
+                              "int_diff", "int_dir_diff")],
+        route.ctypes.data_as(C.POINTER(C.c_int32))))
+    o["sym_route"] = route
+    return o
+
+
+def calc_matrices_lw_eig(dz, gamma1, gamma2, emiss_rate, dscale=None):
+    lib = load_library()
+    g1, g2, b = _fstack(gamma1), _fstack(gamma2), _fstack(emiss_rate)
+    nmat, n, _ = g1.shape
+    d1 = _fstack(dscale) if dscale is not None else None
+    z = lambda *s: np.zeros(s, order="F")  # noqa: E731
+    o = dict(reflectance=z(nmat, n, n), transmittance=z(nmat, n, n), source=z(nmat, n),
+             int_flux=z(nmat, n, n), int_flux_source=z(nmat, n))
+    _check_units(lib.ss_calc_matrices_lw_eig(
+        C.c_int32(nmat), C.c_int32(n), C.c_double(dz), _fp(g1), _fp(g2), _fp(b), _fp(d1),
+        *[_fp(o[k]) for k in ("reflectance", "transmittance", "source", "int_flux", "int_flux_source")]))
+    return o
+
+
+def eigen_decomposition_real(amat, force_general_loops=False):
+    """(eigenvalues (nmat, n), eigenvectors (nmat, n, n), ierr (nmat)) of a stack of matrices."""
+    lib = load_library()
+    a = _fstack(amat)
+    nmat, n, _ = a.shape
+    val = np.zeros((nmat, n), order="F")
+    vec = np.zeros((nmat, n, n), order="F")
+    ierr = np.zeros(nmat, dtype=np.int32)
+    _check_units(lib.ss_eigen_decomposition_real(
+        C.c_int32(n), C.c_int32(nmat), _fp(a), _fp(val), _fp(vec), C.c_int32(int(force_general_loops)),
+        ierr.ctypes.data_as(C.POINTER(C.c_int32))))
+    return val, vec, ierr
 
 
 class Plan:

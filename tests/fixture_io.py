@@ -167,17 +167,24 @@ def rel_errors(got, expected, floor=1.0e-3, zero_floor=1.0e-9):
 # Parity bar (BASELINE.json north_star): fluxes within 1e-5 relative of the
 # reference.  Where the reference's own fp64 result is farther than that from
 # the exact-arithmetic value of its algorithm (degenerate eigen-spectra of
-# identical regions, cancellation in thin layers; measured with the binary128
-# build of the oracle plus the sensitivity to last-bit input perturbations and
-# stored in the fixture), no fp64 implementation can match it more closely than
-# that noise.  For such a variable
-#   (1) the bar is applied ELEMENT BY ELEMENT: |got - ref| <= max(1e-5, 4 x the
-#       reference's own noise at that element) - one ill-conditioned element does
-#       not loosen the bar of the others;
-#   (2) the result must be as good an fp64 evaluation as the reference's: its
-#       distance from exact arithmetic (binary128) is at most
-#       max(1e-5, 4 x the reference's distance from exact arithmetic).
-# (2) is what keeps a bar of 0.2 or 50 from being vacuous.
+# identical regions, cancellation in thin layers), no fp64 implementation can
+# match it more closely than that noise.  The noise is measured, not assumed:
+# the binary128 build of the oracle gives the exact-arithmetic result, and the
+# reference's distance from it is taken over five evaluations that are equivalent
+# at input precision (layer thicknesses changed by a few ulp); fixtures store it
+# per variable (max) and per element.  For a variable whose noise widens the bar
+# (NOISE_FACTOR x noise > PARITY_TOL) the result must
+#   (0) stay within max(1e-5, 4 x noise_var) of the reference everywhere, and
+#   (A) reproduce the reference ELEMENT BY ELEMENT, |got - ref| <= max(1e-5,
+#       4 x the reference's own noise at that element) - one ill-conditioned
+#       element does not loosen the bar of the others -, or
+#   (B) be at least as close to exact arithmetic as the reference's own error
+#       scale: max |got - binary128| <= max(1e-5, noise_var), factor ONE.
+# (A) alone would reject an evaluation whose rounding noise falls on other
+# elements than the reference's although it is more accurate overall (a different
+# but equivalent operation order; measured on rami4pilps with 5 and 7 streams:
+# 6e-5 from exact arithmetic where the reference is 9e-4); (B) is what keeps a
+# bar of 0.2 or 50 from being vacuous.
 PARITY_TOL = 1.0e-5
 NOISE_FACTOR = 4.0
 
@@ -188,7 +195,7 @@ def parity_report(got, expected, ref_noise, truth=None, noise_arr=None, tol=PARI
 
     err            max relative |got - ref|
     bar            max(tol, noise_factor x ref_noise) - the per-variable bar
-    worst_excess   max over elements of err_elem / allowed_elem (per-element bar; <= 1 passes)
+    worst_excess   max over elements of err_elem / allowed_elem (per-element bar; <= 1 passes (A))
     gpu_vs_truth / ref_vs_truth   max relative distance from the binary128 result
     """
     truth = truth or {}
@@ -200,20 +207,22 @@ def parity_report(got, expected, ref_noise, truth=None, noise_arr=None, tol=PARI
         bar = max(tol, noise_factor * n)
         r = {"err": float("inf") if e is None else float(np.max(e)), "bar": bar, "ref_noise": n}
         ok = e is not None and r["err"] <= bar
-        if ok and bar > tol:
+        if e is not None and bar > tol:
+            cond_a = cond_b = None
             if k in noise_arr and noise_arr[k].shape == e.shape:
                 allowed = np.maximum(tol, noise_factor * noise_arr[k] * (1.0 + 1.0e-6) + 1.0e-30)
                 r["worst_excess"] = float(np.max(e / allowed))
-                ok = ok and r["worst_excess"] <= 1.0
+                cond_a = r["worst_excess"] <= 1.0
             if k in truth:
-                t = {k: truth[k]}
                 # both distances in the metric of the reference (same denominators)
                 eg = rel_error_arrays({k: got[k] - truth[k] + expected[k]}, {k: expected[k]})[k]
                 er = rel_error_arrays({k: truth[k]}, {k: expected[k]})[k]
                 if eg is not None and er is not None:
                     r["gpu_vs_truth"] = float(np.max(eg))
                     r["ref_vs_truth"] = float(np.max(er))
-                    ok = ok and r["gpu_vs_truth"] <= max(tol, noise_factor * r["ref_vs_truth"])
+                    cond_b = r["gpu_vs_truth"] <= max(tol, n)
+            if cond_a is not None or cond_b is not None:
+                ok = ok and bool(cond_a or cond_b)
         r["ok"] = bool(ok)
         rep[k] = r
     return rep
@@ -233,6 +242,13 @@ def parity_violations(got, expected, ref_noise, tol=PARITY_TOL, noise_factor=NOI
             bad.append((k, r["err"], r["bar"], {x: r[x] for x in ("worst_excess", "gpu_vs_truth", "ref_vs_truth")
                                               if x in r}))
     return bad
+
+
+def noise_from_truth(ref, truth):
+    """(per-variable scalar noise, per-element noise arrays) of a reference result
+    against the binary128 evaluation of the same inputs."""
+    arr = {k: v for k, v in rel_error_arrays(truth, ref).items() if v is not None}
+    return {k: float(np.max(v)) for k, v in arr.items()}, arr
 
 
 def max_rel_error(got, expected, floor=1.0e-3):

@@ -68,9 +68,19 @@ def _worker(rank, world, port, result_dict):
                                 want_profiles=True, do_simple_spectrum=True)
     local = fixture_io.flatten_outputs(out)
     full = distributed.gather_flat_outputs(local, ranges, layer_ranges, cp.ncol, cp.ntotlay, dist)
+    # the device-to-device gather of the HIP path (pack, ONE gather to rank 0, unpack), driven
+    # here over host arrays: same result as the per-array padded all_gather
+    g = distributed.DeviceGather(distributed.HostArrays(local), dist, mine["canopy"].ncol,
+                                 mine["canopy"].ntotlay)
+    g()
     if rank == 0:
         result_dict.update({k: v for k, v in full.items()})
         result_dict["__ranges__"] = ranges
+        packed = g.to_host()
+        result_dict["__packed_equal__"] = bool(
+            set(packed) == set(full) and all(np.array_equal(packed[k].reshape(full[k].shape), full[k])
+                                             for k in full))
+        result_dict["__packed_bytes__"] = int(g.bytes_per_rank)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -90,10 +100,43 @@ def test_two_rank_shard_and_gather_matches_single_process():
                                 want_profiles=True, do_simple_spectrum=True)
     ref = fixture_io.flatten_outputs(ref)
     ranges = result["__ranges__"]
+    assert result["__packed_equal__"] and result["__packed_bytes__"] > 0
     assert ranges[0][0] == 1 and ranges[-1][1] == case["canopy"].ncol
     assert all(ranges[i][1] + 1 == ranges[i + 1][0] for i in range(len(ranges) - 1))
     for k, v in ref.items():
         assert np.array_equal(result[k], v), k
+
+
+def test_device_gather_with_an_empty_shard():
+    """More ranks than columns with layers: a rank with an empty shard takes part in the
+    gather (its slot of the packed buffer is all padding)."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_worker_empty, args=(2, port, result), nprocs=2, join=True)
+    assert result["ok"], result.get("why")
+
+
+def _worker_empty(rank, world, port, result):
+    import torch.distributed as dist
+    from spartacus_surface_amd import distributed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ncol, nlay, nspec = (3, 7, 2) if rank == 0 else (0, 0, 2)
+    rng = np.random.default_rng(rank)
+    local = {"bc_out.sw_albedo": rng.random((ncol, nspec)), "sw_norm_dir.ground_dn": rng.random((ncol, nspec)),
+             "sw_norm_dir.veg_abs": rng.random((nlay, nspec)), "sw_norm_dir.veg_sunlit_frac": rng.random(nlay)}
+    g = distributed.DeviceGather(distributed.HostArrays(local), dist, ncol, nlay)
+    g()
+    if rank == 0:
+        got = g.to_host()
+        ok = all(np.array_equal(got[k].reshape(local[k].shape), local[k]) for k in local)
+        result["ok"] = bool(ok)
+        result["why"] = "" if ok else "assembled arrays differ"
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def test_shard_ranges_balance_and_edges():

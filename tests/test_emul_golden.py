@@ -54,7 +54,10 @@ def test_emulated_kernels_vs_golden(emul, path):
         lim, bar = REFERENCE_SINGULAR[name]
         expected = {k: v for k, v in expected.items() if noise.get(k, 0.0) <= lim}
         noise = {k: bar / fixture_io.NOISE_FACTOR for k in noise}
-    bad = fixture_io.parity_violations(got, expected, noise)
+    singular = name in REFERENCE_SINGULAR
+    bad = fixture_io.parity_violations(got, expected, noise,
+                                       truth=None if singular else case["ref_truth"],
+                                       noise_arr=None if singular else case["ref_noise_arr"])
     assert not bad, "outside the parity bar: %s" % bad[:5]
 
 
@@ -70,6 +73,7 @@ def test_emulated_ragged_all_tile_types_vs_oracle(emul):
     assert nfail == 0
     ref = fixture_io.flatten_outputs(checker.run_oracle(*a, want_profiles=True)[0])
     truth = fixture_io.flatten_outputs(checker.run_oracle(*a, want_profiles=True, quad=True)[0])
-    bad = fixture_io.parity_violations(fixture_io.flatten_outputs(out), ref,
-                                       fixture_io.rel_errors(ref, truth))
+    noise, noise_arr = fixture_io.noise_from_truth(ref, truth)
+    bad = fixture_io.parity_violations(fixture_io.flatten_outputs(out), ref, noise, truth=truth,
+                                       noise_arr=noise_arr)
     assert not bad, bad[:5]

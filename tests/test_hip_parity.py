@@ -27,6 +27,33 @@ pytestmark = pytest.mark.gpu
 # variables the reference itself gets right to 1e-3 must agree to 5e-2.
 REFERENCE_SINGULAR = {"simple__test_noscat": (1.0e-3, 5.0e-2)}
 
+# Every comparison of this module leaves its full report here: per case and variable
+# {measured error, bar, the reference's own noise, both distances from binary128}.
+# Written to gpurun_out/parity_report.json at the end of the session; the copy of the
+# round's final GPU run is committed as profiles/parity_r2.json.
+_REPORT = {}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_parity_report():
+    yield
+    if not _REPORT:
+        return
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_dir = os.path.join(root, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    worst = {}
+    for label, rep in _REPORT.items():
+        over = {k: r for k, r in rep.items() if r["bar"] > fixture_io.PARITY_TOL}
+        worst[label] = {"variables": len(rep), "max_err": max(r["err"] for r in rep.values()),
+                        "widened_bars": len(over),
+                        "max_err_where_bar_is_1e-5": max([r["err"] for r in rep.values()
+                                                          if r["bar"] <= fixture_io.PARITY_TOL] or [0.0])}
+    with open(os.path.join(out_dir, "parity_report.json"), "w") as f:
+        json.dump({"tol": fixture_io.PARITY_TOL, "noise_factor": fixture_io.NOISE_FACTOR,
+                   "summary": worst, "cases": _REPORT}, f, indent=1, sort_keys=True)
+
 
 def _hip():
     from spartacus_surface_amd import radsurf
@@ -59,7 +86,11 @@ def test_golden_host_entry(path):
         lim, bar = REFERENCE_SINGULAR[name]
         expected = {k: v for k, v in expected.items() if noise.get(k, 0.0) <= lim}
         noise = {k: bar / fixture_io.NOISE_FACTOR for k in noise}
-    bad = fixture_io.parity_violations(got, expected, noise)
+    singular = name in REFERENCE_SINGULAR
+    bad = fixture_io.parity_violations(got, expected, noise,
+                                       truth=None if singular else case["ref_truth"],
+                                       noise_arr=None if singular else case["ref_noise_arr"],
+                                       collect=_REPORT, label="golden/" + name)
     assert not bad, "outside the parity bar: %s" % bad[:5]
 
 
@@ -85,7 +116,8 @@ def test_golden_plan_api_with_device_spectrum(name):
     assert plan.kernel_ms("total") > 0.0
     for k in outs[0]:
         assert np.array_equal(outs[0][k], outs[1][k]), k
-    bad = fixture_io.parity_violations(outs[0], expected, case["ref_noise"])
+    bad = fixture_io.parity_violations(outs[0], expected, case["ref_noise"], truth=case["ref_truth"],
+                                       noise_arr=case["ref_noise_arr"])
     assert not bad, bad[:5]
     plan.close()
 
@@ -107,7 +139,8 @@ def test_fortran_shim_boundary(name, nblock):
     out, _ = checker.run_shim(case["config"], case["canopy"], case["sw"], case["lw"],
                               want_profiles=True, nblocksize=nblock,
                               do_simple_spectrum=case["do_simple_spectrum"])
-    bad = fixture_io.parity_violations(fixture_io.flatten_outputs(out), expected, case["ref_noise"])
+    bad = fixture_io.parity_violations(fixture_io.flatten_outputs(out), expected, case["ref_noise"],
+                                       truth=case["ref_truth"], noise_arr=case["ref_noise_arr"])
     assert not bad, bad[:5]
 
 
@@ -156,7 +189,7 @@ def test_error_behaviour():
                         out["sw_norm_diff"], out["lw_internal"], out["lw_norm"])
 
 
-def _check_against_oracle(case, ncheck):
+def _check_against_oracle(case, ncheck, label=None):
     """Solve the whole case on the GPU (plan API) and compare its first ncheck
     columns with the CPU oracle under the parity bar; the reference's own
     rounding error per variable is measured on the spot with the binary128
@@ -179,10 +212,11 @@ def _check_against_oracle(case, ncheck):
     ref = fixture_io.flatten_outputs(checker.run_oracle(*a, want_profiles=prof, nthreads=8)[0])
     truth = fixture_io.flatten_outputs(checker.run_oracle(*a, want_profiles=prof, nthreads=8,
                                                           quad=True)[0])
-    noise = fixture_io.rel_errors(ref, truth)
+    noise, noise_arr = fixture_io.noise_from_truth(ref, truth)
     nl = int(head["canopy"].ntotlay)
     sl = lambda a: a[:ncheck] if a.shape[0] == cp.ncol else a[:nl]   # noqa: E731
-    bad = fixture_io.parity_violations({k: sl(v) for k, v in got.items()}, ref, noise)
+    bad = fixture_io.parity_violations({k: sl(v) for k, v in got.items()}, ref, noise, truth=truth,
+                                       noise_arr=noise_arr, collect=_REPORT if label else None, label=label)
     return got, bad
 
 
@@ -191,21 +225,21 @@ def test_synthetic_c3_vs_oracle():
     size the oracle finishes in seconds."""
     from spartacus_surface_amd import workloads
     case = workloads.c3_vegetated_urban(ncol=4096, seed=12345)
-    _, bad = _check_against_oracle(case, 4096)
+    _, bad = _check_against_oracle(case, 4096, "synthetic/c3_4096")
     assert not bad, bad[:5]
 
 
 def test_synthetic_c2_vs_oracle():
     from spartacus_surface_amd import workloads
     case = workloads.c2_rami4pilps(ncol=4600)
-    _, bad = _check_against_oracle(case, 4600)
+    _, bad = _check_against_oracle(case, 4600, "synthetic/c2_4600")
     assert not bad, bad[:5]
 
 
 def test_synthetic_c4_mixed_multiband_vs_oracle():
     from spartacus_surface_amd import workloads
     case = workloads.c4_mixed(ncol=512, seed=12345)
-    _, bad = _check_against_oracle(case, 512)
+    _, bad = _check_against_oracle(case, 512, "synthetic/c4_512")
     assert not bad, bad[:5]
 
 
@@ -215,7 +249,7 @@ def test_ragged_all_tile_types_vs_oracle():
     from spartacus_surface_amd import workloads
     case = workloads.ragged_all_tiles(ncol=640, seed=99)
     case["want_profiles"] = True
-    _, bad = _check_against_oracle(case, 640)
+    _, bad = _check_against_oracle(case, 640, "synthetic/ragged_all_tiles_640")
     assert not bad, bad[:5]
 
 
@@ -289,3 +323,88 @@ def test_pipes_and_chunking_do_not_change_results(monkeypatch):
         other = run(pipes, mb)
         for k, v in base.items():
             assert np.array_equal(v, other[k]), (pipes, mb, k)
+
+
+def _host_entry(radsurf, case, out, i0=1, i1=None):
+    cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
+    radsurf.radsurf(cfg, cp, sw, lw, out["bc_out"], i0, cp.ncol if i1 is None else i1, out["sw_norm_dir"],
+                    out["sw_norm_diff"], out["lw_internal"], out["lw_norm"])
+    return fixture_io.flatten_outputs(out)
+
+
+def _sentinel_outputs(case, value=12345.678):
+    out = _alloc(case)
+    for a in fixture_io.flatten_outputs(out).values():
+        a[...] = value
+    return out
+
+
+def test_host_entry_chunks_blocks_and_seeding(monkeypatch):
+    """spartacus_radsurf_hip's pipeline is invisible in the results:
+    (i) the column chunks that alternate between its two device plans (forced small
+    here) give the same bits as one chunk; (ii) a driver that calls with a different
+    16-column block every time (driver/spartacus_surface_driver.F90:206-233) gets the
+    same bits and re-uses the two plans - none is re-created; (iii) skipping the upload of
+    the caller's output arrays where every element is written anyway (canopy columns in
+    daylight) equals always seeding them, on sentinel-filled outputs: no element of the
+    range is left unwritten."""
+    from spartacus_surface_amd import workloads
+    radsurf = _hip()
+    mixed = workloads.ragged_all_tiles(ncol=700, seed=5)
+    mixed["want_profiles"] = True
+    day = workloads.c4_mixed(ncol=700, seed=6, nsw=2, nlw=2)     # canopy columns only, sun up
+    day["want_profiles"] = True
+    assert float(day["canopy"].cos_sza.min()) > 0.0
+    for case in (mixed, day):
+        monkeypatch.delenv("SPARTACUS_HOST_CHUNK", raising=False)
+        monkeypatch.setenv("SPARTACUS_ALWAYS_SEED", "1")
+        base = _host_entry(radsurf, case, _sentinel_outputs(case))
+        monkeypatch.delenv("SPARTACUS_ALWAYS_SEED")
+        lean = _host_entry(radsurf, case, _sentinel_outputs(case))
+        monkeypatch.setenv("SPARTACUS_HOST_CHUNK", "96")
+        chunked = _host_entry(radsurf, case, _sentinel_outputs(case))
+        monkeypatch.delenv("SPARTACUS_HOST_CHUNK")
+        n0 = radsurf.host_entry_plan_creations()
+        out = _sentinel_outputs(case)
+        ncol = case["canopy"].ncol
+        for i0 in range(1, ncol + 1, 16):
+            blocks = _host_entry(radsurf, case, out, i0, min(ncol, i0 + 15))
+        assert radsurf.host_entry_plan_creations() == n0, "block calls re-created the device plans"
+        for k, v in base.items():
+            assert np.array_equal(v, lean[k]), ("seed", k)
+            assert np.array_equal(v, chunked[k]), ("chunk", k)
+            assert np.array_equal(v, blocks[k]), ("blocks", k)
+
+
+def test_plan_follows_its_device_and_streams_are_per_plan():
+    """Two plans alive at once own their streams (no process-global stream state):
+    interleaved solves give the same bits as solving them one after the other, and
+    ss_set_device does not disturb a live plan."""
+    from oracle import checker
+    from spartacus_surface_amd import workloads
+    radsurf = _hip()
+    cases = [workloads.c3_vegetated_urban(ncol=3000, seed=s) for s in (1, 2)]
+
+    def dl(plan, case):
+        out = checker.alloc_outputs(case["config"], case["canopy"], False)
+        plan.download(out["bc_out"], out["sw_norm_dir"], out["sw_norm_diff"], out["lw_internal"], out["lw_norm"])
+        return fixture_io.flatten_outputs(out)
+
+    solo = []
+    for c in cases:
+        p = radsurf.Plan(c["config"], c["canopy"], c["sw"], c["lw"], want_profiles=False)
+        p.solve()
+        solo.append(dl(p, c))
+        p.close()
+    plans = [radsurf.Plan(c["config"], c["canopy"], c["sw"], c["lw"], want_profiles=False) for c in cases]
+    assert plans[0].device() == 0
+    for _ in range(3):
+        for p in plans:
+            p.solve()               # queued on each plan's own streams, no synchronisation in between
+    radsurf.set_device(0)
+    both = [dl(p, c) for p, c in zip(plans, cases)]
+    for p in plans:
+        p.close()
+    for a, b in zip(solo, both):
+        for k, v in a.items():
+            assert np.array_equal(v, b[k]), k

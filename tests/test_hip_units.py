@@ -1,0 +1,232 @@
+"""Kernel-level known answers on the device (gpu): the layer-matrix units of the
+hot path launched alone through the C-ABI (ss_calc_matrices_sw_eig / _lw_eig,
+ss_eigen_decomposition_real - the same __device__ bodies the solver kernels
+inline) against the CPU oracle, for every matrix order the reference's tests
+reach (n = 1, 2, 3, 4, 6, 8, 12):
+
+* seeded Gamma sets shaped like the solver's (tests/test_oracle_vs_reference.py,
+  where the same sets pin the oracle to the compiled reference);
+* Gamma sets with the hidden symmetry of the physical ones, so that orders 3..6
+  take the symmetric eigen-route, including strongly graded spectra that trip
+  sym_spectrum_is_well_graded (fallback to the general route) and identical
+  regions (degenerate spectrum);
+* the inputs of the reference's own driver/test_sw.F90:39-42 with its printed
+  results;
+* the register-resident eigen-solver of orders 3..6 against the run-time-loop form
+  of the same arithmetic, bit for bit, on the device.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip():
+    from spartacus_surface_amd import radsurf
+    radsurf.load_library()
+    assert radsurf.device_count() >= 1
+    return radsurf
+
+
+def _oracle():
+    from oracle import checker
+    if not checker.have_oracle():
+        checker.build(ref=False)
+    return checker
+
+
+def _gamma_like(rng, nmat, n, d):
+    """As tests/test_oracle_vs_reference.py: gamma1 diagonally dominant with a negative
+    diagonal, gamma2 small and positive."""
+    g2 = rng.uniform(0.0, 0.05, (nmat, n, n))
+    g1 = rng.uniform(0.0, 0.02, (nmat, n, n)) + g2
+    for i in range(n):
+        g1[:, i, i] = -rng.uniform(0.3, 2.0, nmat) - np.abs(g1).sum(axis=1)[:, i]
+    g0 = rng.uniform(0.0, 0.05, (nmat, d, d))
+    for i in range(d):
+        g0[:, i, i] = -rng.uniform(0.3, 2.0, nmat) - g0.sum(axis=1)[:, i]
+    g3 = rng.uniform(0.0, 0.1, (nmat, n, d))
+    return g0, g1, g2, g3
+
+
+def _physical_gammas(rng, nmat, nreg, ns, ext_lo=1.0e-2, ext_hi=1.0, identical=False):
+    """Gamma matrices with the structure of radsurf_forest_sw.F90:329-387: regions of
+    fraction f_r exchanging through rates with detailed balance, streams with
+    Legendre-Gauss weights, in-region scattering w_to / mu_from.  Returns
+    (g0, g1, g2, g3, dscale0, dscale); diag(d)^-1 (g1 - g2) diag(d) etc. are symmetric."""
+    from spartacus_surface_amd.legendre_gauss import LegendreGauss
+    lg = LegendreGauss(ns)
+    mu, w, tan = np.array(lg.mu), np.array(lg.weight), np.array(lg.tan_ang)
+    n = nreg * ns
+    g0 = np.zeros((nmat, nreg, nreg)); g1 = np.zeros((nmat, n, n)); g2 = np.zeros((nmat, n, n))
+    g3 = np.zeros((nmat, n, nreg)); d0 = np.zeros((nmat, nreg)); d1 = np.zeros((nmat, n))
+    for m in range(nmat):
+        f = rng.uniform(0.1, 1.0, nreg)
+        f /= f.sum()
+        ext = np.exp(rng.uniform(np.log(ext_lo), np.log(ext_hi), nreg))
+        ssa = rng.uniform(0.1, 0.9, nreg)
+        if identical:
+            ext[:] = ext[0]
+            ssa[:] = ssa[0]
+        perim = rng.uniform(0.01, 0.2, (nreg, nreg))
+        perim = 0.5 * (perim + perim.T)                  # shared boundary: symmetric
+        fx = perim / (np.pi * f[None, :])                # rate out of region "from" (column)
+        np.fill_diagonal(fx, 0.0)
+        mu0 = rng.uniform(0.2, 0.9)
+        tan0 = np.sqrt(1.0 - mu0 * mu0) / mu0
+        for jf in range(nreg):
+            for jt in range(nreg):
+                if jf == jt:
+                    continue
+                g0[m, jf, jf] -= tan0 * fx[jt, jf]
+                g0[m, jt, jf] = tan0 * fx[jt, jf]
+                for s in range(ns):
+                    g1[m, s + jf * ns, s + jf * ns] -= tan[s] * fx[jt, jf]
+                    g1[m, s + jt * ns, s + jf * ns] = tan[s] * fx[jt, jf]
+        for r in range(nreg):
+            g0[m, r, r] -= ext[r] / mu0
+            for s in range(ns):
+                g1[m, s + r * ns, s + r * ns] -= ext[r] / mu[s]
+                g3[m, s + r * ns, r] = 0.5 * w[s] * ext[r] * ssa[r]
+                for s2 in range(ns):
+                    g2[m, s + r * ns, s2 + r * ns] = 0.5 * w[s] * ext[r] * ssa[r] / mu[s2]
+        g1[m] += g2[m]
+        d0[m] = np.sqrt(f)
+        d1[m] = np.repeat(np.sqrt(f), ns) * np.tile(np.sqrt(w * mu), nreg)
+    return g0, g1, g2, g3, d0, d1
+
+
+def _close(a, b, rtol, what):
+    scale = max(1.0e-300, float(np.max(np.abs(b))))
+    err = float(np.max(np.abs(np.asarray(a) - np.asarray(b)))) / scale
+    assert err <= rtol, "%s: %.3e > %.1e" % (what, err, rtol)
+
+
+SW_KEYS = ("reflectance", "transmittance", "s_up", "s_dn", "trans_dir", "int_dir", "int_diff", "int_dir_diff")
+LW_KEYS = ("reflectance", "transmittance", "source", "int_flux", "int_flux_source")
+
+
+@pytest.mark.parametrize("n,d", [(1, 1), (2, 1), (2, 2), (3, 3), (4, 2), (6, 3), (8, 2), (12, 3)])
+def test_calc_matrices_sw_eig_general_route(n, d):
+    """Seeded Gamma sets without the physical symmetry: every order on the general route."""
+    radsurf, chk = _hip(), _oracle()
+    rng = np.random.default_rng(200 + n)
+    g0, g1, g2, g3 = _gamma_like(rng, 70, n, d)          # more than one wave, ragged last wave
+    o = chk.calc_matrices_sw_eig(2.5, 0.6, g0, g1, g2, g3, "oracle")
+    h = radsurf.calc_matrices_sw_eig(2.5, 0.6, g0, g1, g2, g3)
+    assert not h["sym_route"].any()
+    for k in SW_KEYS:
+        _close(h[k], o[k], 1.0e-10, "%s n=%d" % (k, n))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 6, 8, 12])
+def test_calc_matrices_lw_eig_general_route(n):
+    radsurf, chk = _hip(), _oracle()
+    rng = np.random.default_rng(300 + n)
+    _, g1, g2, _ = _gamma_like(rng, 70, n, 1)
+    b = rng.uniform(0.0, 5.0, (70, n))
+    o = chk.calc_matrices_lw_eig(3.0, g1, g2, b, "oracle")
+    h = radsurf.calc_matrices_lw_eig(3.0, g1, g2, b)
+    for k in LW_KEYS:
+        _close(h[k], o[k], 1.0e-10, "%s n=%d" % (k, n))
+
+
+@pytest.mark.parametrize("nreg,ns", [(3, 1), (2, 2), (3, 2)])
+def test_symmetric_route_and_its_fallback(nreg, ns):
+    """Physically structured Gamma sets: moderate spectra take the symmetric route,
+    spectra graded over many decades fall back (sym_spectrum_is_well_graded, some
+    lanes of a wave on each route), identical regions give a degenerate spectrum;
+    all agree with the oracle, which follows the reference's general route."""
+    radsurf, chk = _hip(), _oracle()
+    n = nreg * ns
+    rng = np.random.default_rng(900 + n)
+    for tag, kw, want_sym, rtol in (("moderate", dict(ext_lo=5.0e-2, ext_hi=1.0), True, 1.0e-9),
+                                    ("graded", dict(ext_lo=1.0e-8, ext_hi=1.0), None, 1.0e-6),
+                                    ("identical", dict(identical=True), None, 1.0e-6)):
+        g0, g1, g2, g3, d0, d1 = _physical_gammas(rng, 66, nreg, ns, **kw)
+        o = chk.calc_matrices_sw_eig(1.7, 0.5, g0, g1, g2, g3, "oracle")
+        h = radsurf.calc_matrices_sw_eig(1.7, 0.5, g0, g1, g2, g3, d0, d1)
+        if want_sym and n >= 3:
+            assert h["sym_route"].all(), tag
+        for k in SW_KEYS:
+            _close(h[k], o[k], rtol, "sw %s %s n=%d" % (tag, k, n))
+        b = rng.uniform(0.5, 5.0, (66, n))
+        ol = chk.calc_matrices_lw_eig(1.7, g1, g2, b, "oracle")
+        hl = radsurf.calc_matrices_lw_eig(1.7, g1, g2, b, d1)
+        for k in LW_KEYS:
+            _close(hl[k], ol[k], rtol, "lw %s %s n=%d" % (tag, k, n))
+
+
+def test_graded_physical_spectrum_declines_symmetric_route():
+    """A clear region of extinction 1e-7 next to dense vegetation: the symmetric QL would
+    lose the small eigenvalues; the unit must decline it (route 0) and still match."""
+    radsurf, chk = _hip(), _oracle()
+    rng = np.random.default_rng(77)
+    g0, g1, g2, g3, d0, d1 = _physical_gammas(rng, 64, 3, 2, ext_lo=1.0e-8, ext_hi=1.0)
+    ev = np.linalg.eigvals(np.einsum("mij,mjk->mik", g1 - g2, g1 + g2))
+    span = np.abs(ev).min(axis=1) / np.abs(ev).max(axis=1)
+    o = chk.calc_matrices_sw_eig(2.0, 0.5, g0, g1, g2, g3, "oracle")
+    h = radsurf.calc_matrices_sw_eig(2.0, 0.5, g0, g1, g2, g3, d0, d1)
+    assert (span < 1.0e-7).any(), "test set has no strongly graded spectrum"
+    assert not h["sym_route"][span < 1.0e-7].any()
+    for k in ("reflectance", "transmittance", "s_up", "s_dn", "trans_dir"):
+        _close(h[k], o[k], 1.0e-7, k)
+
+
+def test_known_answer_of_the_reference_driver_test_sw():
+    """driver/test_sw.F90:39-42 (n = 2, d = 2, dz = 2, mu0 = 0.25882; the literals there are
+    default-real, so the inputs are their float32-rounded values) and the results the
+    reference prints for them."""
+    radsurf, chk = _hip(), _oracle()
+    f = np.float32
+    rowmajor = lambda v: np.array([f(x) for x in v], dtype=np.float64).reshape(2, 2)[None]   # noqa: E731
+    g0 = rowmajor([-0.32359, 0.3849, 0.096224, -1.1987])
+    g1 = rowmajor([-0.141379, 0.0446576, 0.178631, -0.586107])
+    g2 = rowmajor([0.00880136, 0.0, 0.0, 0.0115973])
+    g3 = rowmajor([0.0189622, 0.0, 0.0, 0.0227582])
+    dz, mu0 = float(f(2.0)), float(f(0.25882))
+    h = radsurf.calc_matrices_sw_eig(dz, mu0, g0, g1, g2, g3)
+    o = chk.calc_matrices_sw_eig(dz, mu0, g0, g1, g2, g3, "oracle")
+    for k in SW_KEYS:
+        _close(h[k], o[k], 1.0e-12, k)
+    printed = {"reflectance": [[.01363701, .00075426], [.00301703, .00907252]],
+               "transmittance": [[.76295582, .04483029], [.17932177, .31654457]],
+               "trans_dir": [[.54716656, .19476223], [.04869005, .10435450]],
+               "s_dn": [[.02465971, .00605673], [.00466963, .00909060]],
+               "s_up": [[.02537910, .00553554], [.00397927, .01346349]]}
+    for k, v in printed.items():
+        got = np.asarray(h[k])[0]
+        v = np.array(v)
+        assert np.allclose(got, v, rtol=0, atol=2.0e-8) or np.allclose(got.T, v, rtol=0, atol=2.0e-8), (k, got)
+
+
+@pytest.mark.parametrize("n", [3, 4, 5, 6])
+def test_static_eigen_solver_equals_loop_form_bit_for_bit(n):
+    """Orders 3..6: the register-resident, fully predicated shifted-QR (ss_eigen_static.hpp)
+    against the run-time-loop form of the same arithmetic (ss_eigen.hpp), on the device."""
+    radsurf = _hip()
+    rng = np.random.default_rng(100 + n)
+    _, g1, g2, _ = _gamma_like(rng, 200, n, 1)
+    a = np.einsum("mij,mjk->mik", g1 - g2, g1 + g2)
+    # plus isolated / triangular / repeated-eigenvalue matrices (balancing and deflation paths)
+    special = [np.diag(-np.arange(1.0, n + 1)), -np.eye(n), np.triu(rng.uniform(-1, -0.1, (n, n))),
+               np.tril(rng.uniform(-1, -0.1, (n, n)))]
+    a = np.concatenate([a, np.stack(special)], axis=0)
+    v1, x1, e1 = radsurf.eigen_decomposition_real(a)
+    v2, x2, e2 = radsurf.eigen_decomposition_real(a, force_general_loops=True)
+    assert np.array_equal(e1, e2)
+    assert np.array_equal(v1, v2), "eigenvalues differ"
+    assert np.array_equal(x1, x2), "eigenvectors differ"
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 6, 8, 12])
+def test_eigen_decomposition_vs_oracle(n):
+    radsurf, chk = _hip(), _oracle()
+    rng = np.random.default_rng(100 + n)
+    _, g1, g2, _ = _gamma_like(rng, 70, n, 1)
+    a = np.einsum("mij,mjk->mik", g1 - g2, g1 + g2)
+    v_o, x_o = chk.eigen_decomposition_real(a, "oracle")
+    v, x, ierr = radsurf.eigen_decomposition_real(a)
+    assert not ierr.any()
+    assert np.allclose(v, v_o, rtol=1e-12, atol=0)
+    assert np.allclose(x, x_o, rtol=1e-10, atol=1e-13)
