@@ -133,7 +133,7 @@ def _object_scales(expected):
     return scales
 
 
-def rel_error_arrays(got, expected, floor=1.0e-3, zero_floor=1.0e-9):
+def rel_error_arrays(got, expected, floor=1.0e-3, zero_floor=1.0e-9, scales=None):
     """Per-variable, per-element error metric:
         |got - ref| / max(|ref|, floor * max|ref_v|, zero_floor * S_obj)
     where S_obj is the flux scale of the object the variable belongs to; the
@@ -142,7 +142,8 @@ def rel_error_arrays(got, expected, floor=1.0e-3, zero_floor=1.0e-9):
     compared relative to their own rounding noise.  A variable with NaN/inf
     anywhere maps to None."""
     out = {}
-    scales = _object_scales(expected)
+    if scales is None:       # (pass the scales of the full output set when comparing a subset of it)
+        scales = _object_scales(expected)
     for k, ref in expected.items():
         if ref.size == 0 or k not in got:
             continue
@@ -201,6 +202,7 @@ def parity_report(got, expected, ref_noise, truth=None, noise_arr=None, tol=PARI
     truth = truth or {}
     noise_arr = noise_arr or {}
     rep = {}
+    scales = _object_scales(expected)
     errs = rel_error_arrays(got, expected)
     for k, e in errs.items():
         n = float(ref_noise.get(k, 0.0))
@@ -215,8 +217,8 @@ def parity_report(got, expected, ref_noise, truth=None, noise_arr=None, tol=PARI
                 cond_a = r["worst_excess"] <= 1.0
             if k in truth:
                 # both distances in the metric of the reference (same denominators)
-                eg = rel_error_arrays({k: got[k] - truth[k] + expected[k]}, {k: expected[k]})[k]
-                er = rel_error_arrays({k: truth[k]}, {k: expected[k]})[k]
+                eg = rel_error_arrays({k: got[k] - truth[k] + expected[k]}, {k: expected[k]}, scales=scales)[k]
+                er = rel_error_arrays({k: truth[k]}, {k: expected[k]}, scales=scales)[k]
                 if eg is not None and er is not None:
                     r["gpu_vs_truth"] = float(np.max(eg))
                     r["ref_vs_truth"] = float(np.max(er))

@@ -46,7 +46,15 @@ def _gamma_like(rng, nmat, n, d):
     for i in range(d):
         g0[:, i, i] = -rng.uniform(0.3, 2.0, nmat) - g0.sum(axis=1)[:, i]
     g3 = rng.uniform(0.0, 0.1, (nmat, n, d))
-    return g0, g1, g2, g3
+    # The solver's matrices always have a real spectrum ((G1-G2)(G1+G2) is similar to a
+    # symmetric matrix, ss_eigen_sym.hpp); random ones of order >= 6 sometimes do not.  With a
+    # complex pair the reference's formulas (lambda = sqrt(max(0, Re ev)), real/imaginary parts as
+    # two eigenvector columns) stop being an eigen-relation, and algebraically equivalent
+    # evaluation orders - the device's and the reference's - give different numbers, neither of
+    # which means anything.  Keep the matrices with a real spectrum.
+    ev = np.linalg.eigvals(np.einsum("mij,mjk->mik", g1 - g2, g1 + g2))
+    keep = ~(np.abs(ev.imag) > 0).any(axis=1) & (ev.real > 0).all(axis=1)
+    return g0[keep], g1[keep], g2[keep], g3[keep]
 
 
 def _physical_gammas(rng, nmat, nreg, ns, ext_lo=1.0e-2, ext_hi=1.0, identical=False):
@@ -111,24 +119,26 @@ def test_calc_matrices_sw_eig_general_route(n, d):
     """Seeded Gamma sets without the physical symmetry: every order on the general route."""
     radsurf, chk = _hip(), _oracle()
     rng = np.random.default_rng(200 + n)
-    g0, g1, g2, g3 = _gamma_like(rng, 70, n, d)          # more than one wave, ragged last wave
+    g0, g1, g2, g3 = _gamma_like(rng, 140, n, d)         # more than one wave, ragged last wave
     o = chk.calc_matrices_sw_eig(2.5, 0.6, g0, g1, g2, g3, "oracle")
     h = radsurf.calc_matrices_sw_eig(2.5, 0.6, g0, g1, g2, g3)
     assert not h["sym_route"].any()
+    # same algorithm, different (equivalent) operation order and fused multiply-adds: agreement
+    # to rounding times the conditioning of the eigenvector matrices (measured <= 5e-10 at n = 6)
     for k in SW_KEYS:
-        _close(h[k], o[k], 1.0e-10, "%s n=%d" % (k, n))
+        _close(h[k], o[k], 1.0e-8, "%s n=%d" % (k, n))
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 6, 8, 12])
 def test_calc_matrices_lw_eig_general_route(n):
     radsurf, chk = _hip(), _oracle()
     rng = np.random.default_rng(300 + n)
-    _, g1, g2, _ = _gamma_like(rng, 70, n, 1)
-    b = rng.uniform(0.0, 5.0, (70, n))
+    _, g1, g2, _ = _gamma_like(rng, 140, n, 1)
+    b = rng.uniform(0.0, 5.0, (g1.shape[0], n))
     o = chk.calc_matrices_lw_eig(3.0, g1, g2, b, "oracle")
     h = radsurf.calc_matrices_lw_eig(3.0, g1, g2, b)
     for k in LW_KEYS:
-        _close(h[k], o[k], 1.0e-10, "%s n=%d" % (k, n))
+        _close(h[k], o[k], 1.0e-8, "%s n=%d" % (k, n))
 
 
 @pytest.mark.parametrize("nreg,ns", [(3, 1), (2, 2), (3, 2)])
@@ -141,7 +151,8 @@ def test_symmetric_route_and_its_fallback(nreg, ns):
     n = nreg * ns
     rng = np.random.default_rng(900 + n)
     for tag, kw, want_sym, rtol in (("moderate", dict(ext_lo=5.0e-2, ext_hi=1.0), True, 1.0e-9),
-                                    ("graded", dict(ext_lo=1.0e-8, ext_hi=1.0), None, 1.0e-6),
+                                    # air_ext >= 1e-5 is the reference's own floor (read_input :259)
+                                    ("graded", dict(ext_lo=1.0e-5, ext_hi=1.0), None, 1.0e-6),
                                     ("identical", dict(identical=True), None, 1.0e-6)):
         g0, g1, g2, g3, d0, d1 = _physical_gammas(rng, 66, nreg, ns, **kw)
         o = chk.calc_matrices_sw_eig(1.7, 0.5, g0, g1, g2, g3, "oracle")
@@ -158,11 +169,11 @@ def test_symmetric_route_and_its_fallback(nreg, ns):
 
 
 def test_graded_physical_spectrum_declines_symmetric_route():
-    """A clear region of extinction 1e-7 next to dense vegetation: the symmetric QL would
+    """A clear region of extinction ~1e-5 next to dense vegetation: the symmetric QL would
     lose the small eigenvalues; the unit must decline it (route 0) and still match."""
     radsurf, chk = _hip(), _oracle()
     rng = np.random.default_rng(77)
-    g0, g1, g2, g3, d0, d1 = _physical_gammas(rng, 64, 3, 2, ext_lo=1.0e-8, ext_hi=1.0)
+    g0, g1, g2, g3, d0, d1 = _physical_gammas(rng, 64, 3, 2, ext_lo=1.0e-5, ext_hi=1.0)
     ev = np.linalg.eigvals(np.einsum("mij,mjk->mik", g1 - g2, g1 + g2))
     span = np.abs(ev).min(axis=1) / np.abs(ev).max(axis=1)
     o = chk.calc_matrices_sw_eig(2.0, 0.5, g0, g1, g2, g3, "oracle")
@@ -200,33 +211,69 @@ def test_known_answer_of_the_reference_driver_test_sw():
         assert np.allclose(got, v, rtol=0, atol=2.0e-8) or np.allclose(got.T, v, rtol=0, atol=2.0e-8), (k, got)
 
 
+def _eig_agree(a, v1, x1, v2, x2):
+    """Largest differences of two eigen-decompositions of the stack a: eigenvalues relative to the
+    spectral radius, eigenvectors after normalising every column to unit length and sign."""
+    # the order in which eigenvalues deflate out of the QR iteration depends on rounding: compare as sets
+    v1, x1, v2, x2 = np.asarray(v1), np.asarray(x1), np.asarray(v2), np.asarray(x2)
+    i1, i2 = np.argsort(v1, axis=1), np.argsort(v2, axis=1)
+    v1, v2 = np.take_along_axis(v1, i1, axis=1), np.take_along_axis(v2, i2, axis=1)
+    x1, x2 = np.take_along_axis(x1, i1[:, None, :], axis=2), np.take_along_axis(x2, i2[:, None, :], axis=2)
+    dv = float(np.max(np.abs(v1 - v2) / np.max(np.abs(v2), axis=1, keepdims=True)))
+
+    def norm(x):
+        x = x / np.linalg.norm(x, axis=1, keepdims=True)
+        big = np.take_along_axis(x, np.argmax(np.abs(x), axis=1)[:, None, :], axis=1)
+        return x * np.sign(big)
+    dx = float(np.max(np.abs(norm(x1) - norm(x2))))
+    return dv, dx
+
+
 @pytest.mark.parametrize("n", [3, 4, 5, 6])
-def test_static_eigen_solver_equals_loop_form_bit_for_bit(n):
+def test_static_eigen_solver_equals_loop_form(n):
     """Orders 3..6: the register-resident, fully predicated shifted-QR (ss_eigen_static.hpp)
-    against the run-time-loop form of the same arithmetic (ss_eigen.hpp), on the device."""
+    against the run-time-loop form of the same arithmetic (ss_eigen.hpp), on the device.
+    Compiled by gcc without contraction the two are bit-identical (tests/test_emul_eigen.py);
+    hipcc fuses multiply-adds where the code shape lets it, differently in the unrolled and in
+    the loop form, so ON THE DEVICE they agree to rounding, not bit for bit (first measured in
+    round 2: this test used to claim bit-identity).  The bound below is eps x the conditioning
+    of the eigenvectors of these sets; the iteration counts (ierr) are equal."""
     radsurf = _hip()
     rng = np.random.default_rng(100 + n)
-    _, g1, g2, _ = _gamma_like(rng, 200, n, 1)
+    _, g1, g2, _ = _gamma_like(rng, 260, n, 1)
     a = np.einsum("mij,mjk->mik", g1 - g2, g1 + g2)
-    # plus isolated / triangular / repeated-eigenvalue matrices (balancing and deflation paths)
-    special = [np.diag(-np.arange(1.0, n + 1)), -np.eye(n), np.triu(rng.uniform(-1, -0.1, (n, n))),
-               np.tril(rng.uniform(-1, -0.1, (n, n)))]
-    a = np.concatenate([a, np.stack(special)], axis=0)
     v1, x1, e1 = radsurf.eigen_decomposition_real(a)
     v2, x2, e2 = radsurf.eigen_decomposition_real(a, force_general_loops=True)
-    assert np.array_equal(e1, e2)
-    assert np.array_equal(v1, v2), "eigenvalues differ"
-    assert np.array_equal(x1, x2), "eigenvectors differ"
+    assert np.array_equal(e1, e2) and not e1.any()
+    dv, dx = _eig_agree(a, v1, x1, v2, x2)
+    assert dv <= 1.0e-13 and dx <= 1.0e-10, (dv, dx)
+    # isolated / triangular / repeated-eigenvalue matrices (balancing and deflation paths):
+    # no rounding is involved in diagonal ones, the triangular ones agree to rounding
+    d = np.stack([np.diag(-np.arange(1.0, n + 1)), -np.eye(n)])
+    v1, x1, _ = radsurf.eigen_decomposition_real(d)
+    v2, x2, _ = radsurf.eigen_decomposition_real(d, force_general_loops=True)
+    assert np.array_equal(v1, v2) and np.array_equal(x1, x2)
+    t = np.stack([np.triu(rng.uniform(-1, -0.1, (n, n))), np.tril(rng.uniform(-1, -0.1, (n, n)))])
+    v1, _, _ = radsurf.eigen_decomposition_real(t)
+    v2, _, _ = radsurf.eigen_decomposition_real(t, force_general_loops=True)
+    assert np.allclose(np.sort(v1, axis=1), np.sort(v2, axis=1), rtol=1e-13, atol=0)
+    assert np.allclose(np.sort(v1, axis=1), np.sort(np.diagonal(t, axis1=1, axis2=2), axis=1), rtol=1e-13, atol=0)
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 6, 8, 12])
 def test_eigen_decomposition_vs_oracle(n):
+    """Eigenvalues and eigenvectors against the oracle (same EISPACK-lineage algorithm, the
+    reference's operation order) and against the definition: A X = X diag(ev)."""
     radsurf, chk = _hip(), _oracle()
     rng = np.random.default_rng(100 + n)
-    _, g1, g2, _ = _gamma_like(rng, 70, n, 1)
+    _, g1, g2, _ = _gamma_like(rng, 140, n, 1)
     a = np.einsum("mij,mjk->mik", g1 - g2, g1 + g2)
     v_o, x_o = chk.eigen_decomposition_real(a, "oracle")
     v, x, ierr = radsurf.eigen_decomposition_real(a)
     assert not ierr.any()
-    assert np.allclose(v, v_o, rtol=1e-12, atol=0)
-    assert np.allclose(x, x_o, rtol=1e-10, atol=1e-13)
+    dv, dx = _eig_agree(a, np.asarray(v), np.asarray(x), np.asarray(v_o), np.asarray(x_o))
+    assert dv <= 1.0e-12 and dx <= 1.0e-8, (dv, dx)
+    x = np.asarray(x)
+    resid = np.einsum("mij,mjk->mik", a, x) - x * np.asarray(v)[:, None, :]
+    rel = np.max(np.abs(resid), axis=(1, 2)) / (np.max(np.abs(a), axis=(1, 2)) * np.max(np.abs(x), axis=(1, 2)))
+    assert float(rel.max()) <= 1.0e-13, float(rel.max())
