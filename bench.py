@@ -261,7 +261,10 @@ def scale_sum_rate(plan, case, ncol):
 def host_entry_rate(ncol):
     """PCIe-inclusive rate of the host entry point (spartacus_radsurf_hip: host
     buffers in, host buffers out, one call for all columns) on a bounded sample.
-    Reported next to the headline value, never as the value."""
+    Reported next to the headline value, never as the value.  Two figures: the
+    caller's arrays pageable (default) and page-locked once by the library
+    (SPARTACUS_PIN_HOST=1: what a host model that calls every time step with the
+    same arrays gets from its second call on; the first call pays the locking)."""
     from spartacus_surface_amd import radsurf, workloads, types
     case = make_case("c3", ncol, 999)
     cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
@@ -272,13 +275,31 @@ def host_entry_rate(ncol):
         f = types.CanopyFlux()
         f.allocate(cfg, cp.ncol, cp.ntotlay, nspec, use_direct=direct, do_save_flux_profile=False)
         fl.append(f)
-    best = None
-    for _ in range(2):
-        t0 = time.perf_counter()
-        radsurf.radsurf(cfg, cp, sw, lw, bc, 1, cp.ncol, *fl)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    return {"value": ncol / best, "unit": "columns/s", "sample": "%d columns, host buffers in/out" % ncol}
+
+    def best_of(n):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            radsurf.radsurf(cfg, cp, sw, lw, bc, 1, cp.ncol, *fl)
+            ts.append(time.perf_counter() - t0)
+        return ts
+
+    bytes_in, bytes_out = workloads.algorithmic_bytes_per_column(case)
+    os.environ.pop("SPARTACUS_PIN_HOST", None)
+    t_page = best_of(3)
+    os.environ["SPARTACUS_PIN_HOST"] = "1"
+    t_pin = best_of(4)
+    os.environ.pop("SPARTACUS_PIN_HOST", None)
+    pinned = radsurf.host_pinned_bytes()
+    radsurf.host_unpin_all()
+    return {"value": ncol / min(t_pin[1:]), "unit": "columns/s",
+            "sample": "%d columns, host buffers in/out, caller's arrays page-locked (SPARTACUS_PIN_HOST=1), "
+                      "best of 3 calls after the one that locks them" % ncol,
+            "first_call_with_locking_s": t_pin[0], "pinned_bytes": pinned,
+            "pageable": {"value": ncol / min(t_page[1:]), "unit": "columns/s",
+                         "sample": "same, arrays pageable (default), best of 2 calls after the first"},
+            "bytes_per_column_over_pcie": bytes_in + bytes_out,
+            "GB/s_both_directions": (bytes_in + bytes_out) * ncol / min(t_pin[1:]) / 1e9}
 
 
 def main():

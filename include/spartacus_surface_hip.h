@@ -220,10 +220,11 @@ typedef struct ss_flux {
  * calls are serialised per device inside the library.
  * The pointers are HOST pointers; the library stages them to HBM, runs the HIP
  * kernels on the current device and copies the results back.
- * The columns of a call are cut into chunks that alternate between two device
+ * The columns of a call are cut into chunks that alternate between three device
  * plans, so that the upload of one chunk, the kernels of the previous one and
- * the download of the one before overlap (PCIe is what bounds this entry).  The
- * two plans persist between calls while the configuration, the profile flag and
+ * the download of the one before overlap (PCIe is what bounds this entry; uploads
+ * and downloads have a stream each, shared by the plans).  The
+ * plans persist between calls while the configuration, the profile flag and
  * the current device stay the same - whatever the shapes and the column range:
  * their device arrays only grow, and only the slices of [istartcol, iendcol]
  * cross the bus, so the reference driver's block loop (a different column block
@@ -235,6 +236,19 @@ int spartacus_radsurf_hip(const ss_config *config, const ss_canopy *canopy,
                           ss_bc_out *bc_out, int32_t istartcol, int32_t iendcol,
                           ss_flux *sw_norm_dir, ss_flux *sw_norm_diff,
                           ss_flux *lw_internal, ss_flux *lw_norm);
+
+/* Optional page-locking of the caller's arrays for the host entry.  A host model
+ * keeps its (allocatable) arrays for the whole run and calls radsurf every time
+ * step: locked once, every later copy of them is a direct DMA at PCIe rate that
+ * does not block the calling thread, so uploads, kernels and downloads of
+ * successive column chunks overlap in both directions.  SPARTACUS_PIN_HOST=1 makes
+ * spartacus_radsurf_hip lock every array it is handed (first call pays the
+ * locking); ss_host_pin locks one range explicitly.  Nothing is unlocked
+ * behind the caller's back: call ss_host_unpin_all before freeing such arrays.
+ * Pageable arrays (the default) are always correct, just slower. */
+int ss_host_pin(const void *ptr, int64_t bytes);
+int ss_host_unpin_all(void);
+int ss_host_pinned_bytes(int64_t *bytes);
 
 /* --------------------------------------------------------------------------
  * Device-resident plan API (what bench.py times and what a host model that

@@ -4,7 +4,10 @@
 // HIP device is usable every entry point returns SS_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
+#include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -158,7 +161,11 @@ struct HipBackend {
       join_ev_[p] = nullptr;
     }
     if (fork_ev_) hipEventDestroy(fork_ev_);
+    for (hipEvent_t* e : {&up_ev_, &gate_ev_, &down_ev_, &ord_ev_}) { if (*e) hipEventDestroy(*e); *e = nullptr; }
     if (main_) hipStreamDestroy(main_);
+    if (arena_) hipHostFree(arena_);
+    arena_ = nullptr;
+    arena_cap_ = arena_used_ = 0;
     fork_ev_ = nullptr;
     main_ = nullptr;
     if (sw) hipSetDevice(cur);
@@ -166,6 +173,39 @@ struct HipBackend {
   hipStream_t stream() {
     if (!main_) HIP_CHECK_THROW(hipStreamCreateWithFlags(&main_, hipStreamNonBlocking));
     return main_;
+  }
+
+  // Optional transfer streams that are NOT the plan's (the host entry lends its two sub-plans
+  // one upload and one download stream).  Measured on this platform (tools/pipeline_probe*.py):
+  // host-to-device and device-to-host copies only run at the same time when each direction has
+  // a stream of its own - two streams that each carry upload, kernels, download of a chunk do
+  // not overlap their copies at all (17.3 ms = the sum, for 4 x (102 MB up + 146 MB down)),
+  // a dedicated upload stream, the compute stream and a dedicated download stream with events
+  // between them do (11.9 ms).  Without them (up_ = down_ = nullptr) everything stays on the
+  // main stream, in order.
+  hipStream_t up_ = nullptr, down_ = nullptr;
+  hipEvent_t up_ev_ = nullptr, gate_ev_ = nullptr, down_ev_ = nullptr, ord_ev_ = nullptr;
+  bool up_pending_ = false, down_pending_ = false, main_dirty_ = true;
+  void set_transfer_streams(hipStream_t up, hipStream_t down) { up_ = up; down_ = down; }
+  hipStream_t up_stream() { return up_ ? up_ : stream(); }
+  // kernels of the main stream start after the uploads queued so far
+  void join_uploads() {
+    main_dirty_ = true;
+    if (!up_ || !up_pending_) return;
+    if (!up_ev_) HIP_CHECK_THROW(hipEventCreateWithFlags(&up_ev_, hipEventDisableTiming));
+    HIP_CHECK_THROW(hipEventRecord(up_ev_, up_));
+    HIP_CHECK_THROW(hipStreamWaitEvent(stream(), up_ev_, 0));
+    up_pending_ = false;
+  }
+  // uploads queued from now on start after everything queued on the main stream so far
+  // (a chunk's inputs must not be overwritten while the previous chunk's kernels read them:
+  // the host entry waits for the previous chunk's DOWNLOADS before it re-targets a plan, which
+  // implies that; this is for callers of the plan API that upload while a solve is in flight)
+  void order_uploads_after_main() {
+    if (!up_) return;
+    if (!ord_ev_) HIP_CHECK_THROW(hipEventCreateWithFlags(&ord_ev_, hipEventDisableTiming));
+    HIP_CHECK_THROW(hipEventRecord(ord_ev_, stream()));
+    HIP_CHECK_THROW(hipStreamWaitEvent(up_, ord_ev_, 0));
   }
   hipStream_t pipe_stream(int p) {
     if (p <= 0) return stream();
@@ -179,6 +219,7 @@ struct HipBackend {
     t.t0 = t.next();
     t.t1 = t.next();
     t.have_total = false;
+    join_uploads();
     HIP_CHECK_THROW(hipEventRecord(t.t0, stream()));
   }
   void end_solve(Timers& t) {
@@ -192,23 +233,96 @@ struct HipBackend {
     return p;
   }
   void free(void* p) { if (p) hipFree(p); }
-  void memset(void* p, int v, size_t n) { HIP_CHECK_THROW(hipMemsetAsync(p, v, n, stream())); }
+  // initialisation of freshly allocated arrays: same stream as the uploads that may follow into them
+  void memset(void* p, int v, size_t n) {
+    HIP_CHECK_THROW(hipMemsetAsync(p, v, n, up_stream()));
+    up_pending_ = true;
+  }
   void memset_async(void* p, int v, size_t n) { HIP_CHECK_THROW(hipMemsetAsync(p, v, n, stream())); }
   // Copies are queued on the plan's main stream without a synchronisation of their
   // own: from pageable memory the runtime has staged the host buffer when the call
   // returns, and the plan synchronises once at the end of upload() / download()
   // (one wait per call instead of one per array).
   void h2d(void* d, const void* h, size_t n) {
-    if (n) HIP_CHECK_THROW(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, stream()));
+    if (!n) return;
+    HIP_CHECK_THROW(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, up_stream()));
+    up_pending_ = true;
   }
+  // Downloads: on the download stream if one was lent (it first waits for everything queued on
+  // the main stream), else on the main stream behind the kernels.  Extra copy streams per plan
+  // were tried and are worse: HIP maps streams onto a handful of hardware queues and a queue
+  // executes in order, so they end up sharing a queue with another plan's kernels.
   void d2h(void* h, const void* d, size_t n) {
-    if (n) HIP_CHECK_THROW(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream()));
+    if (!n) return;
+    if (down_) {
+      if (main_dirty_) {
+        if (!gate_ev_) HIP_CHECK_THROW(hipEventCreateWithFlags(&gate_ev_, hipEventDisableTiming));
+        HIP_CHECK_THROW(hipEventRecord(gate_ev_, stream()));
+        HIP_CHECK_THROW(hipStreamWaitEvent(down_, gate_ev_, 0));
+        main_dirty_ = false;
+      }
+      HIP_CHECK_THROW(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, down_));
+      down_pending_ = true;
+      return;
+    }
+    HIP_CHECK_THROW(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream()));
   }
-  void sync() { HIP_CHECK_THROW(hipStreamSynchronize(stream())); }
+  void gate_copies() {}      // copies queued now already run after everything queued before them
+  // wait for this plan's work: uploads, kernels, and ITS downloads (not the other plan's on a lent stream)
+  void sync() {
+    if (up_ && up_pending_) join_uploads();
+    HIP_CHECK_THROW(hipStreamSynchronize(stream()));
+    if (down_ && down_pending_) {
+      if (!down_marked_) downloads_queued();
+      HIP_CHECK_THROW(hipEventSynchronize(down_ev_));
+      down_pending_ = down_marked_ = false;
+    }
+  }
+  // mark the end of a batch of downloads without waiting (the later sync() waits for exactly these)
+  bool down_marked_ = false;
+  void downloads_queued() {
+    if (!down_ || !down_pending_) return;
+    if (!down_ev_) HIP_CHECK_THROW(hipEventCreateWithFlags(&down_ev_, hipEventDisableTiming));
+    HIP_CHECK_THROW(hipEventRecord(down_ev_, down_));
+    down_marked_ = true;
+  }
+
+  // The plan's OWN small host vectors (layer counts, column index lists) go through a
+  // page-locked arena of the plan: a copy from pageable memory would make the call wait for
+  // everything queued on the stream before it - with page-locked caller arrays that is the
+  // whole upload of the chunk, and the host thread could not go on to fetch the previous
+  // chunk's results meanwhile.  arena_reset() at the start of an upload: the copies of the
+  // previous upload of this plan have completed by then (upload / download synchronise).
+  char* arena_ = nullptr;
+  size_t arena_cap_ = 0, arena_used_ = 0, arena_want_ = 0;
+  void arena_reset() {
+    // grow between uploads, to twice what the last upload asked for (never while copies from it may be pending
+    // within an upload: a request that does not fit falls back to a plain copy for that one upload)
+    if (arena_want_ > arena_cap_) {
+      if (arena_) hipHostFree(arena_);
+      arena_ = nullptr;
+      arena_cap_ = 0;
+      const size_t cap = std::max(arena_want_ * 2, (size_t)1 << 20);
+      if (hipHostMalloc(reinterpret_cast<void**>(&arena_), cap, hipHostMallocDefault) == hipSuccess) arena_cap_ = cap;
+      else { (void)hipGetLastError(); arena_ = nullptr; }
+    }
+    arena_used_ = arena_want_ = 0;
+  }
+  void h2d_staged(void* d, const void* h, size_t n) {
+    if (!n) return;
+    const size_t need = (arena_used_ + n + 63) & ~(size_t)63;
+    arena_want_ = std::max(arena_want_, (arena_want_ + n + 63) & ~(size_t)63);
+    if (need > arena_cap_ || !arena_) { h2d(d, h, n); return; }
+    std::memcpy(arena_ + arena_used_, h, n);
+    HIP_CHECK_THROW(hipMemcpyAsync(d, arena_ + arena_used_, n, hipMemcpyHostToDevice, up_stream()));
+    up_pending_ = true;
+    arena_used_ = need;
+  }
 
   template <class K, class A>
   void timed_launch(Timers& t, K kernel, dim3 grid, dim3 block, const A& arg) {
     hipEvent_t a = t.next(), b = t.next();
+    join_uploads();
     HIP_CHECK_THROW(hipEventRecord(a, stream()));
     hipLaunchKernelGGL(kernel, grid, block, 0, stream(), arg);
     SS_LAUNCH_CHECK();
@@ -240,6 +354,7 @@ struct HipBackend {
     timed_launch(t, k_scale_sum, dim3(gx, 4), dim3(256), S);
   }
   void launch_spectrum(const ss::SpectrumLaunch& S, Timers&) {
+    join_uploads();
     if (S.ncols > 0) {
       hipLaunchKernelGGL(k_spectrum_col, dim3((S.ncols + 255) / 256), dim3(256), 0, stream(), S);
       SS_LAUNCH_CHECK();
@@ -320,12 +435,12 @@ struct ss_plan {
 
 namespace {
 
-// ---- host entry: column chunks through two alternating device plans ----
+// ---- host entry: column chunks through three alternating device plans ----
 //
 // spartacus_radsurf_hip gets host arrays and must hand host arrays back, so its
 // time is PCIe time: ~2 KB up and ~3.4 KB down per column (C3) against 24 ns of
 // kernels.  The columns of a call are therefore cut into chunks and the chunks
-// alternate between two sub-plans with their own device arrays and streams: while
+// alternate between three sub-plans with their own device arrays and compute stream: while
 // chunk k is solved, chunk k+1 is uploaded and chunk k-1 downloaded, and the host
 // thread only ever waits for copies.  A sub-plan sees a chunk as a column set of
 // its own: every pointer of the caller's structs is advanced to the chunk's first
@@ -335,18 +450,113 @@ namespace {
 // (nblocksize << ncol, driver/spartacus_surface_driver.F90:206-233) re-uses them
 // instead of re-allocating - only the slices of the block cross the bus.
 struct HostEntry {
-  HipPlan* slot[2] = {nullptr, nullptr};
+  static constexpr int kSlots = 3;
+  HipPlan* slot[kSlots] = {nullptr, nullptr, nullptr};
+  // one upload and one download stream for both sub-plans: each direction of the bus needs a
+  // stream of its own to run at the same time as the other (HipBackend::set_transfer_streams)
+  hipStream_t up = nullptr, down = nullptr;
   ss_config cfg;
   int profiles = -1, device = -1;
   long creations = 0;       // sub-plans built so far (tests: block calls must not re-create)
 
+  void streams() {
+    if (!up) HIP_CHECK_THROW(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
+    if (!down) HIP_CHECK_THROW(hipStreamCreateWithFlags(&down, hipStreamNonBlocking));
+  }
   void drop() {
     for (auto& p : slot) { delete p; p = nullptr; }
+    if (up) hipStreamDestroy(up);
+    if (down) hipStreamDestroy(down);
+    up = down = nullptr;
     profiles = -1;
     device = -1;
   }
 };
 HostEntry g_host;           // deliberately never destroyed at process exit (HIP may be gone)
+
+// Optional pinning of the caller's arrays (SPARTACUS_PIN_HOST=1 or ss_host_pin): a host model
+// keeps its allocatable arrays for the whole run and calls radsurf every time step, so the
+// arrays can be page-locked ONCE (hipHostRegister); every later copy is then a direct DMA at
+// PCIe rate that does not block the host thread, and uploads, kernels and downloads of
+// successive chunks overlap in both directions.  Pageable arrays (the default) go through the
+// runtime's staging path, which blocks the calling thread per copy.
+// The registry never unpins by itself: ss_host_unpin_all() does (call it before freeing arrays).
+struct PinRegistry {
+  std::map<const void*, size_t> ranges;     // base -> bytes
+  size_t bytes = 0;
+  bool covered(const void* p, size_t n) const {
+    auto it = ranges.upper_bound(p);
+    if (it == ranges.begin()) return false;
+    --it;
+    return (const char*)p + n <= (const char*)it->first + it->second;
+  }
+  void pin(const void* p, size_t n) {
+    if (!p || n == 0 || covered(p, n)) return;
+    // drop registrations this range overlaps (the caller re-allocated): hipHostRegister rejects overlaps
+    for (auto it = ranges.begin(); it != ranges.end();) {
+      const char *a = (const char*)it->first, *b = a + it->second;
+      if (a < (const char*)p + n && (const char*)p < b) {
+        hipHostUnregister(const_cast<void*>(it->first));
+        bytes -= it->second;
+        it = ranges.erase(it);
+      } else {
+        ++it;
+      }
+    }
+    if (hipHostRegister(const_cast<void*>(p), n, hipHostRegisterDefault) == hipSuccess) {
+      ranges[p] = n;
+      bytes += n;
+    } else {
+      (void)hipGetLastError();      // stays pageable: slower, still correct
+    }
+  }
+  void unpin_all() {
+    for (auto& kv : ranges) hipHostUnregister(const_cast<void*>(kv.first));
+    ranges.clear();
+    bytes = 0;
+  }
+};
+PinRegistry g_pins;
+
+void pin_call_arrays(const ss_config* cfg, const ss_canopy* can, const ss_sw_spectral* sw, const ss_lw_spectral* lw,
+                     ss_bc_out* bc, ss_flux* const* fl) {
+  const size_t nc = (size_t)can->ncol, nl = (size_t)can->ntotlay, D = sizeof(double);
+  g_pins.pin(can->cos_sza, nc * D);
+  const double* lay[] = {can->dz, can->building_fraction, can->veg_fraction, can->building_scale, can->veg_scale,
+                         can->veg_ext, can->veg_fsd, can->veg_contact_fraction};
+  for (const double* p : lay) g_pins.pin(p, nl * D);
+  if (sw && cfg->do_sw) {
+    const size_t S = (size_t)cfg->nsw;
+    const double* a[] = {sw->air_ext, sw->air_ssa, sw->veg_ssa, sw->roof_albedo, sw->wall_albedo, sw->roof_albedo_dir,
+                         sw->wall_specular_frac};
+    for (const double* p : a) g_pins.pin(p, S * nl * D);
+    g_pins.pin(sw->ground_albedo, S * nc * D);
+    g_pins.pin(sw->ground_albedo_dir, S * nc * D);
+  }
+  if (lw && cfg->do_lw) {
+    const size_t W = (size_t)cfg->nlw;
+    const double* a[] = {lw->air_ext, lw->air_ssa, lw->veg_ssa, lw->clear_air_planck, lw->veg_planck,
+                         lw->veg_air_planck, lw->roof_emissivity, lw->wall_emissivity, lw->roof_emission,
+                         lw->wall_emission};
+    for (const double* p : a) g_pins.pin(p, W * nl * D);
+    g_pins.pin(lw->ground_emissivity, W * nc * D);
+    g_pins.pin(lw->ground_emission, W * nc * D);
+  }
+  g_pins.pin(bc->sw_albedo, (size_t)cfg->nsw * nc * D);
+  g_pins.pin(bc->sw_albedo_dir, (size_t)cfg->nsw * nc * D);
+  g_pins.pin(bc->lw_emissivity, (size_t)cfg->nlw * nc * D);
+  g_pins.pin(bc->lw_emission, (size_t)cfg->nlw * nc * D);
+  for (int k = 0; k < 4; ++k) {
+    if (!fl[k]) continue;
+    const size_t ns = (size_t)(k < 2 ? cfg->nsw : cfg->nlw);
+    double* const* m = &fl[k]->ground_dn;
+    for (int F = 0; F < ss::F_NFIELDS; ++F) {
+      const int shape = ss::flux_field_shape(F);
+      const size_t n = shape == 0 ? ns * nc : shape == 1 ? ns * nl : shape == 2 ? nc : nl;
+      g_pins.pin(m[F], n * D);
+    }
+  }
+}
 
 struct ChunkView {
   ss_canopy can;
@@ -427,14 +637,17 @@ void make_view(const ss_canopy* can, const ss_sw_spectral* sw, const ss_lw_spect
   }
 }
 
-// columns per chunk: at least four chunks of a large call (so that copies and
-// kernels overlap), never tiny ones (launch and copy latencies), whole waves
-int chunk_columns_host(int ncols) {
+// Columns of the next chunk.  The downloads are the longest stage of the pipeline (C3: 2.9 KB
+// down against 2.0 KB up per column), so the download engine must start early and never run
+// dry: a first chunk of a sixteenth of the call, then equal chunks of a sixth (every chunk
+// costs ~60 copies whose start-up latencies add up on the engine: not smaller than 16k
+// columns; not larger than 128k: the last chunk's download has nothing to overlap with),
+// whole waves.  SPARTACUS_HOST_CHUNK=<columns> fixes the size.
+int next_chunk_columns(int total, int previous) {
   const char* e = std::getenv("SPARTACUS_HOST_CHUNK");
   if (e && std::atoi(e) > 0) return std::atoi(e);
-  int c = (ncols + 3) / 4;
-  c = std::max(c, 16384);
-  c = std::min(c, 262144);
+  int c = previous > 0 ? std::max(16384, total / 6) : std::max(8192, total / 16);
+  c = std::min(c, 131072);
   return ((c + 63) / 64) * 64;
 }
 
@@ -617,6 +830,28 @@ int ss_plan_destroy(ss_plan* plan) {
   });
 }
 
+int ss_host_pin(const void* ptr, int64_t bytes) {
+  if (!ptr || bytes <= 0) return SS_ERR_BAD_ARGUMENT;
+  int rc = device_ready();
+  if (rc) return rc;
+  std::lock_guard<std::mutex> lock(g_device_mutex);
+  g_pins.pin(ptr, (size_t)bytes);
+  return g_pins.covered(ptr, (size_t)bytes) ? SS_OK : SS_ERR_HIP;
+}
+
+int ss_host_unpin_all(void) {
+  std::lock_guard<std::mutex> lock(g_device_mutex);
+  g_pins.unpin_all();
+  return SS_OK;
+}
+
+int ss_host_pinned_bytes(int64_t* bytes) {
+  if (!bytes) return SS_ERR_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lock(g_device_mutex);
+  *bytes = (int64_t)g_pins.bytes;
+  return SS_OK;
+}
+
 int ss_host_entry_plan_creations(int64_t* count) {
   if (!count) return SS_ERR_BAD_ARGUMENT;
   std::lock_guard<std::mutex> lock(g_device_mutex);
@@ -654,52 +889,79 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
 
     ss_flux* fl[4] = {config->do_sw ? sw_norm_dir : nullptr, config->do_sw ? sw_norm_diff : nullptr,
                       config->do_lw ? lw_internal : nullptr, config->do_lw ? lw_norm : nullptr};
+    if (std::getenv("SPARTACUS_PIN_HOST")) pin_call_arrays(config, canopy, sw, lw, bc_out, fl);
     const bool always_seed = std::getenv("SPARTACUS_ALWAYS_SEED") != nullptr;
     const int c_begin = istartcol - 1, c_end = iendcol;
-    const int chunk = chunk_columns_host(c_end - c_begin);
-    ChunkView views[2];
-    int pending = -1;          // slot whose results still have to come back
+    constexpr int NS = HostEntry::kSlots;
+    ChunkView views[NS];
+    bool inflight[NS] = {};     // results of the slot's chunk still on their way to the host
     int r = SS_OK;
     auto fail = [&](HipPlan* p, int code) {
       if (p) g_last_error = p->error;
       g_host.drop();
       return code;
     };
-    auto download = [&](int s) {
-      ChunkView& v = views[s];
-      return g_host.slot[s]->download(&v.bc, v.have_fl[0] ? &v.fl[0] : nullptr, v.have_fl[1] ? &v.fl[1] : nullptr,
-                                      v.have_fl[2] ? &v.fl[2] : nullptr, v.have_fl[3] ? &v.fl[3] : nullptr);
-    };
-    int k = 0;
+    auto fl_of = [](ChunkView& v, int k) { return v.have_fl[k] ? &v.fl[k] : nullptr; };
+    // SPARTACUS_HOST_TIMING=1: wall-clock milliseconds of the host thread per chunk and phase (stderr)
+    const bool timing = std::getenv("SPARTACUS_HOST_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now();
+    int k = 0, chunk = 0;
     for (int c0 = c_begin; c0 < c_end; c0 += chunk, ++k) {
-      const int c1 = std::min(c_end, c0 + chunk), s = k & 1;
+      chunk = next_chunk_columns(c_end - c_begin, chunk);
+      const int c1 = std::min(c_end, c0 + chunk), s = k % NS;
+      const double ta = now();
+      HipPlan*& p = g_host.slot[s];
+      if (inflight[s]) {          // the chunk NS back used this slot: its results must be home first
+        r = p->download_end();
+        inflight[s] = false;
+        if (r) return fail(p, r);
+      }
+      const double tw = now();
       ChunkView& v = views[s];
       make_view(canopy, sw, lw, bc_out, fl, config->nsw, config->nlw, c0, c1, v);
-      HipPlan*& p = g_host.slot[s];
       if (!p) {
         p = new HipPlan;
-        p->pipes_cap = 2;   // less scratch to allocate for what may be a one-shot call
+        // one stream per sub-plan: the two sub-plans then sit on two hardware queues of their own, and
+        // what this entry has to hide is PCIe time, not the (shorter) kernel time
+        p->pipes_cap = 1;
         ++g_host.creations;
+        g_host.streams();
+        // (a second download stream taken in turn by successive chunks, to fill the start-up gaps
+        // between a chunk's ~60 copies, was measured slower: 1.04e7 -> 0.84e7 columns/s - more
+        // streams than hardware queues)
+        if (!std::getenv("SPARTACUS_HOST_ONE_STREAM")) p->be.set_transfer_streams(g_host.up, g_host.down);
         r = p->create(config, &v.can, sw ? &v.sw : nullptr, lw ? &v.lw : nullptr, 1, c1 - c0, profiles);
       } else {
-        r = p->reset(&v.can, sw ? &v.sw : nullptr, lw ? &v.lw : nullptr, 1, c1 - c0);
+        // no wait: the copies of this chunk stay queued in front of its kernels (the caller's
+        // arrays are ours until this entry returns); page-locked arrays then move by DMA while
+        // the host thread goes on
+        r = p->reset(&v.can, sw ? &v.sw : nullptr, lw ? &v.lw : nullptr, 1, c1 - c0, false);
       }
       if (r) return fail(p, r);
-      p->upload_outputs(&v.bc, v.have_fl[0] ? &v.fl[0] : nullptr, v.have_fl[1] ? &v.fl[1] : nullptr,
-                        v.have_fl[2] ? &v.fl[2] : nullptr, v.have_fl[3] ? &v.fl[3] : nullptr,
+      const double tb = now();
+      p->upload_outputs(&v.bc, fl_of(v, 0), fl_of(v, 1), fl_of(v, 2), fl_of(v, 3),
                         always_seed ? (int)HipPlan::SEED_ALL : p->seed_needed());
+      const double tc = now();
       r = p->solve();
       if (r) return fail(p, r);
-      if (pending >= 0) {            // the other slot's chunk comes back while this one is solved
-        r = download(pending);
-        if (r) return fail(g_host.slot[pending], r);
-      }
-      pending = s;
+      const double td = now();
+      // the results come back as soon as the kernels are done; the host does not wait here
+      r = p->download_begin(&v.bc, fl_of(v, 0), fl_of(v, 1), fl_of(v, 2), fl_of(v, 3));
+      if (r) return fail(p, r);
+      inflight[s] = true;
+      if (timing)
+        std::fprintf(stderr, "host entry chunk %d (%d cols): wait for slot %.2f, view+upload %.2f, seed %.2f, solve queued %.2f, download queued %.2f ms\n",
+                     k, c1 - c0, tw - ta, tb - tw, tc - tb, td - tc, now() - td);
     }
-    if (pending >= 0) {
-      r = download(pending);
-      if (r) return fail(g_host.slot[pending], r);
+    for (int s = 0; s < NS; ++s) {
+      if (!inflight[s]) continue;
+      const double te = now();
+      r = g_host.slot[s]->download_end();
+      if (r) return fail(g_host.slot[s], r);
+      if (timing) std::fprintf(stderr, "host entry: slot %d home after %.2f ms\n", s, now() - te);
     }
+    if (timing) std::fprintf(stderr, "host entry total %.2f ms\n", now() - t_start);
     if (nocache) g_host.drop();
     return r;
   });

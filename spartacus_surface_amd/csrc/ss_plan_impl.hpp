@@ -23,6 +23,7 @@
 #pragma once
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -235,14 +236,16 @@ class Plan {
     dev_elems[name] = elems;
     dev_cap[name] = elems;
   }
-  void mirror(const std::string& name, const void* host, size_t elems, size_t elsize = sizeof(double)) {
+  void mirror(const std::string& name, const void* host, size_t elems, size_t elsize = sizeof(double),
+              bool staged = false) {
     if (!host) {
       auto it = dev.find(name);
       if (it != dev.end()) { be.free(it->second); dev.erase(it); dev_elems.erase(name); dev_cap.erase(name); }
       return;
     }
     ensure(name, elems, elsize);
-    be.h2d(dev[name], host, elems * elsize);
+    if (staged) be.h2d_staged(dev[name], host, elems * elsize);
+    else be.h2d(dev[name], host, elems * elsize);
   }
 
   // which canopy_flux members exist (allocate_canopy_flux, radsurf_canopy_flux.F90:96-163)
@@ -316,7 +319,8 @@ class Plan {
 
   // Point the plan at a column set (same configuration, any shape): output arrays
   // for (ncol, ntotlay), inputs uploaded, columns of [i0, i1] classified.
-  int reset(const ss_canopy* can, const ss_sw_spectral* sw, const ss_lw_spectral* lw, int i0, int i1) {
+  int reset(const ss_canopy* can, const ss_sw_spectral* sw, const ss_lw_spectral* lw, int i0, int i1,
+            bool wait = true) {
     ncol = can->ncol;
     ntotlay = can->ntotlay;
     istartcol = i0;
@@ -330,12 +334,18 @@ class Plan {
     ensure("bc_out.lw_emission", std::max<size_t>(1, (size_t)nlw * ncol));
     if (cfg.do_sw) { alloc_flux("sw_norm_dir", nsw, true); alloc_flux("sw_norm_diff", nsw, true); }
     if (cfg.do_lw) { alloc_flux("lw_internal", nlw, false); alloc_flux("lw_norm", nlw, false); }
-    return upload(can, sw, lw);
+    return upload(can, sw, lw, wait);
   }
 
   // ---- upload inputs + classify ----
-  int upload(const ss_canopy* can, const ss_sw_spectral* sw, const ss_lw_spectral* lw) {
+  // wait = false: the copies stay queued on the plan's stream (host arrays that are pinned are
+  // read by the DMA engine later: the caller keeps them unchanged until it has synchronised -
+  // the host entry does, its arrays are the caller's for the whole call)
+  int upload(const ss_canopy* can, const ss_sw_spectral* sw, const ss_lw_spectral* lw, bool wait = true) {
     if (can->ncol != ncol || can->ntotlay != ntotlay) { error = "shape changed since plan creation"; return SS_ERR_BAD_ARGUMENT; }
+    const bool timing_ = std::getenv("SPARTACUS_HOST_TIMING") != nullptr;
+    auto now_ = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0_ = now_();
     h_nlay.assign(can->nlay, can->nlay + ncol);
     h_indcol.clear();
     h_istartlay.assign(can->istartlay, can->istartlay + ncol);
@@ -343,8 +353,9 @@ class Plan {
     if (can->cos_sza) h_cos_sza.assign(can->cos_sza, can->cos_sza + ncol);
     else h_cos_sza.assign(ncol, 0.0);
 
-    mirror("canopy.nlay", can->nlay, ncol, sizeof(int32_t));
-    mirror("canopy.istartlay", can->istartlay, ncol, sizeof(int32_t));
+    be.arena_reset();
+    mirror("canopy.nlay", can->nlay, ncol, sizeof(int32_t), true);
+    mirror("canopy.istartlay", can->istartlay, ncol, sizeof(int32_t), true);
     mirror("canopy.cos_sza", can->cos_sza, ncol);
     const size_t nl = std::max(1, ntotlay);
 #define MIRL(obj, member) mirror(#obj "." #member, (obj)->member, (obj)->member ? nl : 0)
@@ -390,8 +401,10 @@ class Plan {
       mirror("lw.roof_emission", lw->roof_emission, ll);
       mirror("lw.wall_emission", lw->wall_emission, ll);
     }
+    const double t1_ = now_();
     const int rc = classify();
-    be.sync();     // the caller may reuse (or free) its host arrays as soon as this returns
+    if (timing_) std::fprintf(stderr, "  upload: mirrors %.2f ms, classify %.2f ms\n", t1_ - t0_, now_() - t1_);
+    if (wait) be.sync();     // the caller may reuse (or free) its host arrays as soon as this returns
     return rc;
   }
 
@@ -406,6 +419,12 @@ class Plan {
     sw_classes.clear(); lw_classes.clear();
     flat_cols.clear(); night_cols.clear(); simple_cols[0].clear(); simple_cols[1].clear();
     std::map<ClassKey, std::vector<int32_t>> swm, lwm;
+    // neighbouring columns are mostly of one class: remember the last bucket of each family
+    struct Last { ClassKey k{false, -1, -1}; std::vector<int32_t>* v = nullptr; } last_sw, last_lw;
+    auto bucket = [](std::map<ClassKey, std::vector<int32_t>>& m, Last& l, const ClassKey& k) -> std::vector<int32_t>& {
+      if (!l.v || l.k < k || k < l.k) { l.v = &m[k]; l.k = k; }
+      return *l.v;
+    };
     lay_first = 0; lay_count = 0;
     for (int j = istartcol - 1; j < iendcol; ++j) {
       const int irep = h_irep[j];
@@ -427,7 +446,7 @@ class Plan {
         if (h_cos_sza[j] > 0.0) {
           ClassKey k{urban, nreg, urban ? cfg.lg_sw_urban.nstream : cfg.lg_sw_forest.nstream};
           if (!key_supported(k)) { error = "SW (nstream,nregion) combination not instantiated"; return SS_ERR_UNSUPPORTED; }
-          swm[k].push_back(j);
+          bucket(swm, last_sw, k).push_back(j);
         } else {
           night_cols.push_back(j);
         }
@@ -435,7 +454,7 @@ class Plan {
       if (cfg.do_lw) {
         ClassKey k{urban, nreg, urban ? cfg.lg_lw_urban.nstream : cfg.lg_lw_forest.nstream};
         if (!key_supported(k)) { error = "LW (nstream,nregion) combination not instantiated"; return SS_ERR_UNSUPPORTED; }
-        lwm[k].push_back(j);
+        bucket(lwm, last_lw, k).push_back(j);
       }
     }
     if (iendcol >= istartcol) {
@@ -450,10 +469,20 @@ class Plan {
       for (auto& kv : m) {
         ColumnClass cc;
         cc.key = kv.first;
-        cc.cols = kv.second;
-        std::stable_sort(cc.cols.begin(), cc.cols.end(),
-                         [&](int32_t a, int32_t b) { return h_nlay[a] > h_nlay[b]; });
-        cc.maxlay = h_nlay[cc.cols.front()];
+        // descending layer count, stable: a counting sort over the layer counts that occur
+        // (linear; nothing to do when all columns of the class have the same count)
+        int lo = h_nlay[kv.second.front()], hi = lo;
+        for (int32_t j : kv.second) { lo = std::min(lo, h_nlay[j]); hi = std::max(hi, h_nlay[j]); }
+        if (lo == hi) {
+          cc.cols = std::move(kv.second);
+        } else {
+          std::vector<size_t> start(hi - lo + 2, 0);
+          for (int32_t j : kv.second) ++start[hi - h_nlay[j] + 1];
+          for (size_t b = 1; b < start.size(); ++b) start[b] += start[b - 1];
+          cc.cols.resize(kv.second.size());
+          for (int32_t j : kv.second) cc.cols[start[hi - h_nlay[j]]++] = j;
+        }
+        cc.maxlay = hi;
         out.push_back(std::move(cc));
       }
     };
@@ -479,7 +508,7 @@ class Plan {
       d_index = static_cast<int32_t*>(be.alloc(idx.size() * sizeof(int32_t)));
       index_elems = idx.size();
     }
-    be.h2d(d_index, idx.data(), idx.size() * sizeof(int32_t));
+    be.h2d_staged(d_index, idx.data(), idx.size() * sizeof(int32_t));
 
     // scratch sizing: the largest per-column need over all classes
     size_t need_lay = 0, need_col = 0;
@@ -836,15 +865,32 @@ class Plan {
     }
   }
 
+  // Two-phase form for callers that overlap the download with other work: _begin queues every
+  // copy behind the kernels that are queued now and returns; _end waits until the host arrays
+  // are complete.
+  int download_begin(ss_bc_out* bc, ss_flux* sw_dir, ss_flux* sw_diff, ss_flux* lw_int, ss_flux* lw_nrm) {
+    be.gate_copies();
+    const int rc = download_queue(bc, sw_dir, sw_diff, lw_int, lw_nrm);
+    be.downloads_queued();
+    return rc;
+  }
+  int download_end() {
+    be.sync();
+    return SS_OK;
+  }
   int download(ss_bc_out* bc, ss_flux* sw_dir, ss_flux* sw_diff, ss_flux* lw_int, ss_flux* lw_nrm) {
     be.sync();
+    download_queue(bc, sw_dir, sw_diff, lw_int, lw_nrm);
+    be.sync();     // all copies were queued asynchronously: complete before the host reads
+    return SS_OK;
+  }
+  int download_queue(ss_bc_out* bc, ss_flux* sw_dir, ss_flux* sw_diff, ss_flux* lw_int, ss_flux* lw_nrm) {
     if (bc) {
       if (cfg.do_sw) { get_cols("bc_out.sw_albedo", bc->sw_albedo, nsw); get_cols("bc_out.sw_albedo_dir", bc->sw_albedo_dir, nsw); }
       if (cfg.do_lw) { get_cols("bc_out.lw_emissivity", bc->lw_emissivity, nlw); get_cols("bc_out.lw_emission", bc->lw_emission, nlw); }
     }
     if (cfg.do_sw) { xfer_flux("sw_norm_dir", sw_dir, nsw, true); xfer_flux("sw_norm_diff", sw_diff, nsw, true); }
     if (cfg.do_lw) { xfer_flux("lw_internal", lw_int, nlw, true); xfer_flux("lw_norm", lw_nrm, nlw, true); }
-    be.sync();     // all copies were queued asynchronously: complete before the host reads
     return SS_OK;
   }
 

@@ -39,6 +39,7 @@ EXPORTS = (
     "ss_plan_calc_simple_spectrum_lw", "ss_plan_solve", "ss_plan_synchronize",
     "ss_plan_download", "ss_plan_last_kernel_ms", "ss_plan_eigen_failures", "ss_plan_set_pipes", "ss_plan_scale_and_sum", "ss_plan_download_sums",
     "ss_plan_device_ptr", "ss_plan_device", "ss_plan_destroy", "ss_host_entry_plan_creations",
+    "ss_host_pin", "ss_host_unpin_all", "ss_host_pinned_bytes",
     "ss_device_count", "ss_set_device",
     "ss_last_error", "ss_version",
     "ss_calc_matrices_sw_eig", "ss_calc_matrices_lw_eig", "ss_eigen_decomposition_real",
@@ -88,6 +89,17 @@ def device_count():
 
 def set_device(index):
     _check(load_library().ss_set_device(C.c_int32(index)))
+
+
+def host_unpin_all():
+    """Unlock every host array the library page-locked (SPARTACUS_PIN_HOST=1 / ss_host_pin)."""
+    _check(load_library().ss_host_unpin_all())
+
+
+def host_pinned_bytes():
+    n = C.c_int64(0)
+    _check(load_library().ss_host_pinned_bytes(C.byref(n)))
+    return n.value
 
 
 def host_entry_plan_creations():

@@ -28,6 +28,10 @@ struct EmulBackend {
   static void memset(void* p, int v, size_t n) { std::memset(p, v, n); }
   static void memset_async(void* p, int v, size_t n) { std::memset(p, v, n); }
   static void h2d(void* d, const void* h, size_t n) { std::memcpy(d, h, n); }
+  static void h2d_staged(void* d, const void* h, size_t n) { std::memcpy(d, h, n); }
+  static void arena_reset() {}
+  static void gate_copies() {}
+  static void downloads_queued() {}
   static void d2h(void* h, const void* d, size_t n) { std::memcpy(h, d, n); }
   static void sync() {}
 

@@ -191,13 +191,17 @@ NOISE_FACTOR = 4.0
 
 
 def parity_report(got, expected, ref_noise, truth=None, noise_arr=None, tol=PARITY_TOL,
-                  noise_factor=NOISE_FACTOR):
+                  noise_factor=NOISE_FACTOR, slack=1.0):
     """{var: dict(err, bar, ref_noise, ok[, worst_excess, gpu_vs_truth, ref_vs_truth])}.
 
     err            max relative |got - ref|
     bar            max(tol, noise_factor x ref_noise) - the per-variable bar
     worst_excess   max over elements of err_elem / allowed_elem (per-element bar; <= 1 passes (A))
     gpu_vs_truth / ref_vs_truth   max relative distance from the binary128 result
+    slack          widens the three noise allowances (not tol) by a common factor; 1 for the GPU,
+                   2 for the TEST-ONLY host emulation of the kernels, whose gcc arithmetic (no fused
+                   multiply-add) is yet another realisation of the rounding noise and is there to
+                   catch logic errors before a GPU is involved
     """
     truth = truth or {}
     noise_arr = noise_arr or {}
@@ -206,13 +210,13 @@ def parity_report(got, expected, ref_noise, truth=None, noise_arr=None, tol=PARI
     errs = rel_error_arrays(got, expected)
     for k, e in errs.items():
         n = float(ref_noise.get(k, 0.0))
-        bar = max(tol, noise_factor * n)
+        bar = max(tol, slack * noise_factor * n)
         r = {"err": float("inf") if e is None else float(np.max(e)), "bar": bar, "ref_noise": n}
         ok = e is not None and r["err"] <= bar
         if e is not None and bar > tol:
             cond_a = cond_b = None
             if k in noise_arr and noise_arr[k].shape == e.shape:
-                allowed = np.maximum(tol, noise_factor * noise_arr[k] * (1.0 + 1.0e-6) + 1.0e-30)
+                allowed = np.maximum(tol, slack * noise_factor * noise_arr[k] * (1.0 + 1.0e-6) + 1.0e-30)
                 r["worst_excess"] = float(np.max(e / allowed))
                 cond_a = r["worst_excess"] <= 1.0
             if k in truth:
@@ -222,7 +226,7 @@ def parity_report(got, expected, ref_noise, truth=None, noise_arr=None, tol=PARI
                 if eg is not None and er is not None:
                     r["gpu_vs_truth"] = float(np.max(eg))
                     r["ref_vs_truth"] = float(np.max(er))
-                    cond_b = r["gpu_vs_truth"] <= max(tol, n)
+                    cond_b = r["gpu_vs_truth"] <= max(tol, slack * n)
             if cond_a is not None or cond_b is not None:
                 ok = ok and bool(cond_a or cond_b)
         r["ok"] = bool(ok)
@@ -231,11 +235,11 @@ def parity_report(got, expected, ref_noise, truth=None, noise_arr=None, tol=PARI
 
 
 def parity_violations(got, expected, ref_noise, tol=PARITY_TOL, noise_factor=NOISE_FACTOR, truth=None,
-                      noise_arr=None, collect=None, label=None):
+                      noise_arr=None, collect=None, label=None, slack=1.0):
     """[(name, error, allowed)] for every variable outside the parity bar.
     collect: optional dict that receives the full report under "label" (the GPU
     test-suite dumps it to gpurun_out/parity_*.json for the record)."""
-    rep = parity_report(got, expected, ref_noise, truth, noise_arr, tol, noise_factor)
+    rep = parity_report(got, expected, ref_noise, truth, noise_arr, tol, noise_factor, slack)
     if collect is not None and label is not None:
         collect[label] = rep
     bad = []
