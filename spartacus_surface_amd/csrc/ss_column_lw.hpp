@@ -20,7 +20,12 @@ struct LwColRec {
   static constexpr int ABE = PDN + rec_even(N * N);   // a_below(l+1)      N x N (canopy part)
   static constexpr int SBE = ABE + rec_even(N * N);   // source_below(l+1) N (canopy part)
   static constexpr int RSD = SBE + rec_even(N);       // Den^-1 (R source_above + source_lay)  N
-  static constexpr int NELEM = RSD + rec_even(N);
+  // fused layer + upward kernel (fused_order(N)): what the downward sweep reads of the layer
+  // matrices travels here - int_flux_mat (N x N) and int_source (N)
+  static constexpr bool FUSED = fused_order(N, true);
+  static constexpr int IFLUX = RSD + rec_even(N);
+  static constexpr int ISRC = IFLUX + rec_even(N * N);
+  static constexpr int NELEM = FUSED ? ISRC + rec_even(N) : IFLUX;
   // flux at the layer base in the downward sweep = P flux_top + RSD (forest :547-553)
 };
 
@@ -55,125 +60,218 @@ SS_HD void lw_adding_step(const double* Aab, const double* Sab, const double* R,
   }
 }
 
-// ---- section 4: adding method with sources, upward (k_up) ----
+// ---- section 4: adding method with sources, upward ----
+// a_above, source_above at the ground (forest :455-466, urban :554-565)
+template <bool URBAN, int NREG, int NS>
+SS_HD void lw_ground(const Launch& L, long cidx, int l0, double* Aab, double* Sab) {
+  constexpr int N = NREG * NS;
+  const Inputs& in = L.in;
+  const LG& lg = L.lg;
+  mat_zero<N, N>(Aab);
+  const double gem = in.ground_emissivity[cidx], gemission = in.ground_emission[cidx];
+  double frac1[NREG];
+  region_fractions<URBAN, true, NREG>((NREG > 1) ? in.veg_fraction[l0] : 0.0,
+                                      URBAN ? in.building_fraction[l0] : 0.0, frac1);
+  SS_UNROLL_FULL
+  for (int jreg = 0; jreg < NREG; ++jreg) {
+    SS_UNROLL_FULL
+    for (int jsto = 0; jsto < NS; ++jsto) {
+      SS_UNROLL_FULL
+      for (int jsfr = 0; jsfr < NS; ++jsfr)
+        SS_E(Aab, jsto + jreg * NS, jsfr + jreg * NS, N) = (1.0 - gem) * lg.hweight[jsto];
+    }
+    SS_UNROLL_FULL
+    for (int js = 0; js < NS; ++js) Sab[js + jreg * NS] = (lg.hweight[js] * frac1[jreg]) * gemission;
+  }
+}
+
+// Adding step of one layer: R, T, source_lay from "src"; stores a_below, source_below and the
+// operators of the downward sweep into the column record
+template <int N, class Src>
+SS_HD void lw_up_step(const Src& src, const double* Aab, const double* Sab, double* crec, double* Abe, double* Sbe) {
+  using LRec = LwRec<N>;
+  using CRec = LwColRec<N>;
+  constexpr long stride = kRecStride;
+  double R[N * N], T[N * N], Den[N * N], Sl[N];
+  src.template load<N * N>(LRec::R, R);
+  src.template load<N * N>(LRec::T, T);
+  src.template load<N>(LRec::SRC, Sl);
+  lw_adding_step<N>(Aab, Sab, R, T, Sl, Den, Abe, Sbe);
+  rec_store<N * N>(crec, stride, CRec::ABE, Abe);
+  rec_store<N>(crec, stride, CRec::SBE, Sbe);
+  // operators of the downward sweep
+  lu_solve_mat<N, N>(Den, T);                 // P = Den^-1 T (T is dead afterwards)
+  rec_store<N * N>(crec, stride, CRec::PDN, T);
+  double rs[N];
+  mat_vec<N, N>(R, Sab, rs);
+  SS_UNROLL_N(N)
+  for (int i = 0; i < N; ++i) rs[i] = rs[i] + Sl[i];
+  lu_solve<N>(Den, rs);
+  rec_store<N>(crec, stride, CRec::RSD, rs);
+}
+
+// Overlap to the base of the layer above layer jlay, or to the free atmosphere (forest :495-506,
+// urban :583-626)
+template <bool URBAN, int NREG, int NS>
+SS_HD void lw_overlap_above(const Launch& L, int cu, int jlay, int nlay, const double* Abe, const double* Sbe,
+                            double* Aab, double* Sab) {
+  constexpr int N = NREG * NS;
+  constexpr int DB = URBAN ? NREG + 1 : NREG;
+  const LG& lg = L.lg;
+  double U[NREG * DB], V[DB * NREG];
+  const double* prec = pack_rec(L, jlay, cu, kPackLw);
+  double vf_lo, bf_lo, vf_up = 0.0, bf_up = 0.0;
+  pack_fractions(prec, vf_lo, bf_lo);
+  if (jlay + 1 < nlay) pack_fractions(pack_rec(L, jlay + 1, cu, kPackLw), vf_up, bf_up);
+  interface_overlap_vals<URBAN, true, NREG>(L.cfg.min_vegetation_fraction, jlay + 1 >= nlay, vf_up, bf_up,
+                                            false, vf_lo, bf_lo, U, V);
+  double roof_a = 0.0, roof_emis = 0.0, exposed_roof_frac = 0.0;
+  if (URBAN) {
+    // urban :587-605
+    if (jlay < nlay - 1) exposed_roof_frac = ss_max(0.0, bf_lo - bf_up);
+    else exposed_roof_frac = bf_lo;
+    const RecPair re = rec_pair_load(prec + 14 * kRecStride);   // roof_emissivity, roof_emission
+    roof_a = 1.0 - re.x;
+    roof_emis = re.y;
+  }
+  double tA[N * N], tAroof[NS * N];
+  SS_UNROLL_FULL
+  for (int ju = 0; ju < NREG; ++ju) {
+    SS_UNROLL_FULL
+    for (int s = 0; s < NS; ++s) {
+      const int c = ju * NS + s;
+      SS_UNROLL_N(N)
+      for (int i = 0; i < N; ++i) {
+        double acc = 0.0;
+        SS_UNROLL_FULL
+        for (int jl = 0; jl < NREG; ++jl) acc += SS_E(Abe, i, jl * NS + s, N) * SS_E(V, jl, ju, DB);
+        SS_E(tA, i, c, N) = acc;
+      }
+      SS_UNROLL_FULL
+      for (int sr = 0; sr < NS; ++sr)
+        SS_E(tAroof, sr, c, NS) = URBAN ? (roof_a * lg.hweight[sr]) * SS_E(V, DB - 1, ju, DB) : 0.0;
+    }
+  }
+  apply_U_mat<NREG, DB, NS, N>(U, tA, tAroof, Aab);
+  // source_above(l+1) = (U (x) I) source_below(l+1)   (incl. the roof part)
+  double sroof[NS];
+  SS_UNROLL_FULL
+  for (int s = 0; s < NS; ++s) sroof[s] = URBAN ? lg.hweight[s] * roof_emis * exposed_roof_frac : 0.0;
+  apply_U_mat<NREG, DB, NS, 1>(U, Sbe, sroof, Sab);
+}
+
+template <int NREG, int NS>
+SS_HD void lw_top(const Launch& L, long cidx, const double* Aab, const double* Sab) {
+  constexpr int N = NREG * NS;
+  const LG& lg = L.lg;
+  double s = 0.0;
+  SS_UNROLL_FULL
+  for (int j1 = 0; j1 < NS; ++j1) {
+    double acc = 0.0;
+    SS_UNROLL_FULL
+    for (int j2 = 0; j2 < NS; ++j2) acc += SS_E(Aab, j1, j2, N) * lg.hweight[j2];
+    s += acc;
+  }
+  L.top1[cidx] = 1.0 - s;           // top_emissivity
+  s = 0.0;
+  SS_UNROLL_FULL
+  for (int j1 = 0; j1 < NS; ++j1) s += Sab[j1];
+  L.top2[cidx] = s;                 // top_emission
+}
+
+// The upward sweep as a kernel of its own (k_column; orders above SS_UNROLL_MAX)
 template <bool URBAN, int NREG, int NS>
 SS_HD void column_up_lw(const Launch& L, int cu) {
   constexpr int N = NREG * NS;
-  constexpr int DB = URBAN ? NREG + 1 : NREG;
   using LRec = LwRec<N>;
   using CRec = LwColRec<N>;
   const Inputs& in = L.in;
-  const LG& lg = L.lg;
   const int col = L.cols[cu / L.nspec];
   const int jb = cu % L.nspec;
-  const int nspec = L.nspec;
   const int nlay = in.nlay[col];
   const int l0 = in.istartlay[col] - 1;
-  constexpr long stride = kRecStride;
-  const long cidx = (long)jb + (long)nspec * col;
-
+  const long cidx = (long)jb + (long)L.nspec * col;
   double Aab[N * N], Sab[N];
-  mat_zero<N, N>(Aab);
-  {
-    const double gem = in.ground_emissivity[cidx], gemission = in.ground_emission[cidx];
-    double frac1[NREG];
-    region_fractions<URBAN, true, NREG>((NREG > 1) ? in.veg_fraction[l0] : 0.0,
-                                        URBAN ? in.building_fraction[l0] : 0.0, frac1);
-    SS_UNROLL_FULL
-    for (int jreg = 0; jreg < NREG; ++jreg) {
-      SS_UNROLL_FULL
-      for (int jsto = 0; jsto < NS; ++jsto) {
-        SS_UNROLL_FULL
-        for (int jsfr = 0; jsfr < NS; ++jsfr)
-          SS_E(Aab, jsto + jreg * NS, jsfr + jreg * NS, N) = (1.0 - gem) * lg.hweight[jsto];
-      }
-      SS_UNROLL_FULL
-      for (int js = 0; js < NS; ++js) Sab[js + jreg * NS] = (lg.hweight[js] * frac1[jreg]) * gemission;
-    }
-  }
-
+  lw_ground<URBAN, NREG, NS>(L, cidx, l0, Aab, Sab);
   for (int jlay = 0; jlay < nlay; ++jlay) {
-    const double* lrec = L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu);
+    const RecSource src{L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu), kRecStride};
     double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
-    const int lay = l0 + jlay;
-    const long sidx = (long)jb + (long)nspec * lay;
     double Abe[N * N], Sbe[N];
-    {
-      double R[N * N], T[N * N], Den[N * N], Sl[N];
-      rec_load<N * N>(lrec, stride, LRec::R, R);
-      rec_load<N * N>(lrec, stride, LRec::T, T);
-      rec_load<N>(lrec, stride, LRec::SRC, Sl);
-      lw_adding_step<N>(Aab, Sab, R, T, Sl, Den, Abe, Sbe);
-      rec_store<N * N>(crec, stride, CRec::ABE, Abe);
-      rec_store<N>(crec, stride, CRec::SBE, Sbe);
-      // operators of the downward sweep
-      lu_solve_mat<N, N>(Den, T);                 // P = Den^-1 T (T is dead afterwards)
-      rec_store<N * N>(crec, stride, CRec::PDN, T);
-      double rs[N];
-      mat_vec<N, N>(R, Sab, rs);
-      SS_UNROLL_N(N)
-      for (int i = 0; i < N; ++i) rs[i] = rs[i] + Sl[i];
-      lu_solve<N>(Den, rs);
-      rec_store<N>(crec, stride, CRec::RSD, rs);
-    }
-    {
-      double U[NREG * DB], V[DB * NREG];
-      const double* prec = pack_rec(L, jlay, cu, kPackLw);
-      double vf_lo, bf_lo, vf_up = 0.0, bf_up = 0.0;
-      pack_fractions(prec, vf_lo, bf_lo);
-      if (jlay + 1 < nlay) pack_fractions(pack_rec(L, jlay + 1, cu, kPackLw), vf_up, bf_up);
-      interface_overlap_vals<URBAN, true, NREG>(L.cfg.min_vegetation_fraction, jlay + 1 >= nlay, vf_up, bf_up,
-                                                false, vf_lo, bf_lo, U, V);
-      double roof_a = 0.0, roof_emis = 0.0, exposed_roof_frac = 0.0;
-      if (URBAN) {
-        // urban :587-605
-        if (jlay < nlay - 1) exposed_roof_frac = ss_max(0.0, bf_lo - bf_up);
-        else exposed_roof_frac = bf_lo;
-        const RecPair re = rec_pair_load(prec + 14 * kRecStride);   // roof_emissivity, roof_emission
-        roof_a = 1.0 - re.x;
-        roof_emis = re.y;
-      }
-      double tA[N * N], tAroof[NS * N];
-      SS_UNROLL_FULL
-      for (int ju = 0; ju < NREG; ++ju) {
-        SS_UNROLL_FULL
-        for (int s = 0; s < NS; ++s) {
-          const int c = ju * NS + s;
-          SS_UNROLL_N(N)
-          for (int i = 0; i < N; ++i) {
-            double acc = 0.0;
-            SS_UNROLL_FULL
-            for (int jl = 0; jl < NREG; ++jl) acc += SS_E(Abe, i, jl * NS + s, N) * SS_E(V, jl, ju, DB);
-            SS_E(tA, i, c, N) = acc;
-          }
-          SS_UNROLL_FULL
-          for (int sr = 0; sr < NS; ++sr)
-            SS_E(tAroof, sr, c, NS) = URBAN ? (roof_a * lg.hweight[sr]) * SS_E(V, DB - 1, ju, DB) : 0.0;
-        }
-      }
-      apply_U_mat<NREG, DB, NS, N>(U, tA, tAroof, Aab);
-      // source_above(l+1) = (U (x) I) source_below(l+1)   (incl. the roof part)
-      double sroof[NS];
-      SS_UNROLL_FULL
-      for (int s = 0; s < NS; ++s) sroof[s] = URBAN ? lg.hweight[s] * roof_emis * exposed_roof_frac : 0.0;
-      apply_U_mat<NREG, DB, NS, 1>(U, Sbe, sroof, Sab);
+    lw_up_step<N>(src, Aab, Sab, crec, Abe, Sbe);
+    lw_overlap_above<URBAN, NREG, NS>(L, cu, jlay, nlay, Abe, Sbe, Aab, Sab);
+  }
+  lw_top<NREG, NS>(L, cidx, Aab, Sab);
+}
+
+// Writer of the fused longwave layer stage: R, T -> LDS slots; source_lay -> registers (hold);
+// int_flux_mat and int_source -> column record (read by the downward sweep only)
+template <int N, class Lds>
+struct LwFusedWriter {
+  using LRec = LwRec<N>;
+  using CRec = LwColRec<N>;
+  const Lds* lds;
+  double* hold;           // rec_even(N) elements: source_lay
+  double* crec;
+  long stride;
+  unsigned long long* stamps;
+  SS_HD void put2(int e, double v0, double v1) const {
+    if (e < LRec::IFLUX) {
+      lds->put(e, v0);
+      lds->put(e + 1, v1);
+    } else if (e < LRec::SRC) {
+      rec_pair_store(crec + (long)(CRec::IFLUX + e - LRec::IFLUX) * stride, v0, v1);
+    } else if (e < LRec::ISRC) {
+      hold[e - LRec::SRC] = v0;
+      hold[e + 1 - LRec::SRC] = v1;
+    } else {
+      rec_pair_store(crec + (long)(CRec::ISRC + e - LRec::ISRC) * stride, v0, v1);
     }
   }
+};
 
-  {
-    double s = 0.0;
-    SS_UNROLL_FULL
-    for (int j1 = 0; j1 < NS; ++j1) {
-      double acc = 0.0;
-      SS_UNROLL_FULL
-      for (int j2 = 0; j2 < NS; ++j2) acc += SS_E(Aab, j1, j2, N) * lg.hweight[j2];
-      s += acc;
+// Layer matrices and adding step of every layer of a column unit on one lane (k_layer_up, see
+// the header of the fused kernels in ss_layer_matrices.hpp)
+template <bool URBAN, int NREG, int NS>
+SS_HD void layer_up_lw(const Launch& L, int cu) {
+  constexpr int N = NREG * NS;
+  using LRec = LwRec<N>;
+  using CRec = LwColRec<N>;
+  static_assert(CRec::FUSED && LRec::IFLUX <= kLaneLdsSlots, "fused form needs R and T in the lane's LDS slots");
+  using Lds = LaneLds<true>;
+  constexpr long stride = kRecStride;
+  const Inputs& in = L.in;
+  const int col = L.cols[cu / L.nspec];
+  const int jb = cu % L.nspec;
+  const int nlay = in.nlay[col];
+  const int l0 = in.istartlay[col] - 1;
+  const long cidx = (long)jb + (long)L.nspec * col;
+  const Lds lds{};
+  for (int jlay = 0; jlay < nlay; ++jlay) {
+    double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
+    double hold[LRec::ISRC - LRec::SRC];
+    const LwFusedWriter<N, Lds> w{&lds, hold, crec, stride, (unsigned long long*)L.eigen_fail};
+    layer_unit_lw<URBAN, NREG, NS>(L, cu, jlay, w);
+    double Aab[N * N], Sab[N];
+    if (jlay == 0) {
+      lw_ground<URBAN, NREG, NS>(L, cidx, l0, Aab, Sab);
+    } else {
+      const double* prev = L.col + rec_base(jlay - 1, L.maxlay, CRec::NELEM, cu);
+      double Abe[N * N], Sbe[N];
+      rec_load<N * N>(prev, stride, CRec::ABE, Abe);
+      rec_load<N>(prev, stride, CRec::SBE, Sbe);
+      lw_overlap_above<URBAN, NREG, NS>(L, cu, jlay - 1, nlay, Abe, Sbe, Aab, Sab);
     }
-    L.top1[cidx] = 1.0 - s;           // top_emissivity
-    s = 0.0;
-    SS_UNROLL_FULL
-    for (int j1 = 0; j1 < NS; ++j1) s += Sab[j1];
-    L.top2[cidx] = s;                 // top_emission
+    const FusedSource<LRec::SRC, Lds> src{&lds, hold};
+    double Abe[N * N], Sbe[N];
+    lw_up_step<N>(src, Aab, Sab, crec, Abe, Sbe);
+  }
+  if (nlay > 0) {
+    const double* prev = L.col + rec_base(nlay - 1, L.maxlay, CRec::NELEM, cu);
+    double Abe[N * N], Sbe[N], Aab[N * N], Sab[N];
+    rec_load<N * N>(prev, stride, CRec::ABE, Abe);
+    rec_load<N>(prev, stride, CRec::SBE, Sbe);
+    lw_overlap_above<URBAN, NREG, NS>(L, cu, nlay - 1, nlay, Abe, Sbe, Aab, Sab);
+    lw_top<NREG, NS>(L, cidx, Aab, Sab);
   }
 }
 
@@ -353,8 +451,13 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
 
     // ---- issue group 4 (int_flux), work on group 3: the interface at the base ----
     double IFLUX[N * N], ISRC[N];
-    rec_load<N * N>(lrec, st, LRec::IFLUX, IFLUX);
-    rec_load<N>(lrec, st, LRec::ISRC, ISRC);
+    if (CRec::FUSED) {
+      rec_load<N * N>(crec, st, CRec::IFLUX, IFLUX);
+      rec_load<N>(crec, st, CRec::ISRC, ISRC);
+    } else {
+      rec_load<N * N>(lrec, st, LRec::IFLUX, IFLUX);
+      rec_load<N>(lrec, st, LRec::ISRC, ISRC);
+    }
     SS_LOAD_FENCE();
 
     if (jlay > 0) {
@@ -495,7 +598,8 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
 template <bool URBAN, int NREG, int NS>
 SS_HD void column_unit_lw(const Launch& L, int cu) {
   double slot = 0.0;
-  column_up_lw<URBAN, NREG, NS>(L, cu);
+  if constexpr (LwColRec<NREG * NS>::FUSED) layer_up_lw<URBAN, NREG, NS>(L, cu);
+  else column_up_lw<URBAN, NREG, NS>(L, cu);
   column_down_lw<URBAN, NREG, NS>(L, cu, 0, &slot);
   column_down_lw<URBAN, NREG, NS>(L, cu, 1, &slot);
 }

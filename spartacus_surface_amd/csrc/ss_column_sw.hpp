@@ -30,7 +30,19 @@ struct SwColRec {
   static constexpr int QDN = PDN + rec_even(N * N);       // Q = Den^-1 (R d_above E + S_dn)  N x D
   static constexpr int ABE = QDN + rec_even(N * D);       // a_below(l+1)      N x N (canopy part)
   static constexpr int DBE = ABE + rec_even(N * N);       // d_below(l+1)      N x D (canopy part)
-  static constexpr int NELEM = DBE + rec_even(N * D);
+  // fused layer + upward kernel (fused_order(N)): no layer record exists, and what the downward
+  // sweep reads of it travels in the column record: trans_dir_dir (E) and int_dir, D x D each
+  static constexpr bool FUSED = fused_order(N, false);
+#if defined(SS_FUSE_VIA_RECORD)
+  // variant: S_up, S_dn also pass through the column record (re-read by the adding step) instead
+  // of staying in registers across the layer stage; tail = [S_up S_dn E int_dir] as in SwRec
+  static constexpr int TAIL = DBE + rec_even(N * D);
+  static constexpr int EDIR = TAIL + 2 * rec_even(N * D);
+#else
+  static constexpr int EDIR = DBE + rec_even(N * D);
+#endif
+  static constexpr int IDIR = EDIR + rec_even(D * D);
+  static constexpr int NELEM = FUSED ? IDIR + rec_even(D * D) : DBE + rec_even(N * D);
   // Den = I - a_above R.  The downward sweep needs the flux at the layer base,
   //   diff_base = Den^-1 (T diff_top + R d_above E dir_top + S_dn dir_top) = P diff_top + Q dir_top,
   // so the two operators are stored instead of LU(Den): the sweep then reads
@@ -68,157 +80,231 @@ struct SwColCtx {
   }
 };
 
-// ---- section 4: adding method upward (k_up) ----
+// ---- section 4: adding method upward ----
+// a_above, d_above at the ground (forest :466-477, urban :594-606)
+template <int NREG, int NS>
+SS_HD void sw_ground_albedo(const LG& lg, double ga, double gad, double cos_sza, double* Aab, double* Dab) {
+  constexpr int N = NREG * NS, D = NREG;
+  mat_zero<N, N>(Aab);
+  mat_zero<N, D>(Dab);
+  SS_UNROLL_FULL
+  for (int jreg = 0; jreg < NREG; ++jreg) {
+    SS_UNROLL_FULL
+    for (int jsto = 0; jsto < NS; ++jsto) {
+      SS_E(Dab, jsto + jreg * NS, jreg, N) = cos_sza * gad * lg.hweight[jsto];
+      SS_UNROLL_FULL
+      for (int jsfr = 0; jsfr < NS; ++jsfr)
+        SS_E(Aab, jsto + jreg * NS, jsfr + jreg * NS, N) = ga * lg.hweight[jsto];
+    }
+  }
+}
+
+// Adding step of one layer (forest :486-493, urban :619-626): consumes R, T, S_up, S_dn, E of
+// the layer from "src" (HBM layer record or the fused layer stage), stores the operators of
+// the downward sweep and a_below / d_below into the column record, returns the latter.
+template <int N, int D, class Src>
+SS_HD void sw_adding_step(const Src& src, const double* Aab, const double* Dab, double* crec,
+                          double* Abe, double* Dbe) {
+  using LRec = SwRec<N, D>;
+  using CRec = SwColRec<N, D>;
+  constexpr long stride = kRecStride;
+  double R[N * N], T[N * N], Den[N * N], X[N * N];
+  src.template load<N * N>(LRec::R, R);
+  src.template load<N * N>(LRec::T, T);
+  SS_LOAD_FENCE(); SS_SCHED_FENCE();   // the loads of E, S_dn, S_up stay where they are written (register pressure)
+  // denominator = I - a_above R
+  mat_mul<N, N, N>(Aab, R, Den);
+  SS_UNROLL_NN(N)
+  for (int k = 0; k < N * N; ++k) Den[k] = -Den[k];
+  SS_UNROLL_N(N)
+  for (int j = 0; j < N; ++j) SS_E(Den, j, j, N) = 1.0 + SS_E(Den, j, j, N);
+  lu_factor<N>(Den);
+  // P = Den^-1 T
+  mat_copy<N, N>(T, X);
+  lu_solve_mat<N, N>(Den, X);
+  rec_store<N * N>(crec, stride, CRec::PDN, X);
+  // a_below = R + T Den^-1 (a_above T)
+  mat_mul<N, N, N>(Aab, T, X);
+  lu_solve_mat<N, N>(Den, X);
+  mat_mul<N, N, N>(T, X, Abe);
+  SS_UNROLL_NN(N)
+  for (int k = 0; k < N * N; ++k) Abe[k] = R[k] + Abe[k];
+  rec_store<N * N>(crec, stride, CRec::ABE, Abe);
+  // d_below = S_up + T Den^-1 (d_above E + a_above S_dn)
+  double E[D * D], S[N * D], Y[N * D];
+  src.template load<D * D>(LRec::EDIR, E);
+  src.template load<N * D>(LRec::SDN, S);
+  mat_mul<N, D, D>(Dab, E, Y);
+  {
+    // Q = Den^-1 (R (d_above E) + S_dn)
+    double Q[N * D];
+    mat_mul<N, N, D>(R, Y, Q);
+    SS_UNROLL_FULL
+    for (int k = 0; k < N * D; ++k) Q[k] = Q[k] + S[k];
+    lu_solve_mat<N, D>(Den, Q);
+    rec_store<N * D>(crec, stride, CRec::QDN, Q);
+  }
+  mat_mul_acc<N, N, D>(Aab, S, Y);
+  lu_solve_mat<N, D>(Den, Y);
+  src.template load<N * D>(LRec::SUP, S);
+  mat_mul<N, N, D>(T, Y, Dbe);
+  SS_UNROLL_FULL
+  for (int k = 0; k < N * D; ++k) Dbe[k] = S[k] + Dbe[k];
+  rec_store<N * D>(crec, stride, CRec::DBE, Dbe);
+}
+
+// Overlap to the base of the layer above layer jlay, or to the free atmosphere
+// (forest :495-503, urban :627-653): a_above = (U x I) [a_below (V x I); roof rows], same for d
+template <bool URBAN, int NREG, int NS>
+SS_HD void sw_overlap_above(const Launch& L, int cu, int jlay, int nlay, double cos_sza, const double* Abe,
+                            const double* Dbe, double* Aab, double* Dab) {
+  constexpr int N = NREG * NS, D = NREG;
+  constexpr int DB = URBAN ? NREG + 1 : NREG;
+  const LG& lg = L.lg;
+  double U[NREG * DB], V[DB * NREG];
+  const double* prec = pack_rec(L, jlay, cu, kPackSw);
+  double vf_lo, bf_lo, vf_up = 0.0, bf_up = 0.0;
+  pack_fractions(prec, vf_lo, bf_lo);
+  if (jlay + 1 < nlay) pack_fractions(pack_rec(L, jlay + 1, cu, kPackSw), vf_up, bf_up);
+  interface_overlap_vals<URBAN, false, NREG>(L.cfg.min_vegetation_fraction, jlay + 1 >= nlay, vf_up, bf_up,
+                                             false, vf_lo, bf_lo, U, V);
+  double roof_a = 0.0, roof_d = 0.0;
+  if (URBAN) {
+    const RecPair ra = rec_pair_load(prec + 8 * kRecStride);   // roof_albedo, roof_albedo_dir
+    roof_a = ra.x;
+    roof_d = cos_sza * ra.y;
+  }
+  // tA = a_below (V (x) I): canopy rows (N x N) and roof rows (NS x N)
+  double tA[N * N], tAroof[NS * N];
+  SS_UNROLL_FULL
+  for (int ju = 0; ju < NREG; ++ju) {
+    SS_UNROLL_FULL
+    for (int s = 0; s < NS; ++s) {
+      const int cc = ju * NS + s;
+      SS_UNROLL_N(N)
+      for (int i = 0; i < N; ++i) {
+        double acc = 0.0;
+        SS_UNROLL_FULL
+        for (int jl = 0; jl < NREG; ++jl) acc += SS_E(Abe, i, jl * NS + s, N) * SS_E(V, jl, ju, DB);
+        SS_E(tA, i, cc, N) = acc;
+      }
+      SS_UNROLL_FULL
+      for (int sr = 0; sr < NS; ++sr)
+        SS_E(tAroof, sr, cc, NS) = URBAN ? (roof_a * lg.hweight[sr]) * SS_E(V, DB - 1, ju, DB) : 0.0;
+    }
+  }
+  apply_U_mat<NREG, DB, NS, N>(U, tA, tAroof, Aab);
+  // tD = d_below V (rect_mat_x_singlemat :462): canopy rows and roof rows
+  double tD[N * D], tDroof[NS * D];
+  SS_UNROLL_FULL
+  for (int ju = 0; ju < NREG; ++ju) {
+    SS_UNROLL_N(N)
+    for (int i = 0; i < N; ++i) {
+      double acc = 0.0;
+      SS_UNROLL_FULL
+      for (int jl = 0; jl < NREG; ++jl) acc += SS_E(Dbe, i, jl, N) * SS_E(V, jl, ju, DB);
+      SS_E(tD, i, ju, N) = acc;
+    }
+    SS_UNROLL_FULL
+    for (int sr = 0; sr < NS; ++sr)
+      SS_E(tDroof, sr, ju, NS) = URBAN ? (roof_d * lg.hweight[sr]) * SS_E(V, DB - 1, ju, DB) : 0.0;
+  }
+  apply_U_mat<NREG, DB, NS, D>(U, tD, tDroof, Dab);
+}
+
+// top-of-canopy albedos (forest :520-528, urban :666-674)
+template <int NREG, int NS>
+SS_HD void sw_top_albedos(const Launch& L, long cidx, double cos_sza, const double* Aab, const double* Dab) {
+  constexpr int N = NREG * NS;
+  const LG& lg = L.lg;
+  double s = 0.0;
+  SS_UNROLL_FULL
+  for (int j1 = 0; j1 < NS; ++j1) {
+    double acc = 0.0;
+    SS_UNROLL_FULL
+    for (int j2 = 0; j2 < NS; ++j2) acc += SS_E(Aab, j1, j2, N) * lg.hweight[j2];
+    s += acc;
+  }
+  L.top1[cidx] = s;
+  s = 0.0;
+  SS_UNROLL_FULL
+  for (int j1 = 0; j1 < NS; ++j1) s += SS_E(Dab, j1, 0, N);
+  L.top2[cidx] = s / cos_sza;
+}
+
+// The upward sweep as a kernel of its own (k_column; orders above SS_UNROLL_MAX)
 template <bool URBAN, int NREG, int NS>
 SS_HD void column_up_sw(const Launch& L, int cu) {
   constexpr int N = NREG * NS, D = NREG;
-  constexpr int DB = URBAN ? NREG + 1 : NREG;
   using LRec = SwRec<N, D>;
   using CRec = SwColRec<N, D>;
   const Inputs& in = L.in;
-  const LG& lg = L.lg;
   const SwColCtx<URBAN, NREG, NS> c(L, cu, false);
-  const int col = c.col, jb = c.jb, nspec = c.nspec, nlay = c.nlay, l0 = c.l0;
-  const long cidx = c.cidx;
-  const double cos_sza = c.cos_sza;
-  constexpr long stride = kRecStride;
-
   double Aab[N * N], Dab[N * D];
-  mat_zero<N, N>(Aab);
-  mat_zero<N, D>(Dab);
-  {
-    const double ga = in.ground_albedo[cidx], gad = in.ground_albedo_dir[cidx];
-    SS_UNROLL_FULL
-    for (int jreg = 0; jreg < NREG; ++jreg) {
-      SS_UNROLL_FULL
-      for (int jsto = 0; jsto < NS; ++jsto) {
-        SS_E(Dab, jsto + jreg * NS, jreg, N) = cos_sza * gad * lg.hweight[jsto];
-        SS_UNROLL_FULL
-        for (int jsfr = 0; jsfr < NS; ++jsfr)
-          SS_E(Aab, jsto + jreg * NS, jsfr + jreg * NS, N) = ga * lg.hweight[jsto];
-      }
-    }
-  }
-
-  for (int jlay = 0; jlay < nlay; ++jlay) {
-    const double* lrec = L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu);
+  sw_ground_albedo<NREG, NS>(L.lg, in.ground_albedo[c.cidx], in.ground_albedo_dir[c.cidx], c.cos_sza, Aab, Dab);
+  for (int jlay = 0; jlay < c.nlay; ++jlay) {
+    const RecSource src{L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu), kRecStride};
     double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
-    const long sidx = (long)jb + (long)nspec * (l0 + jlay);
     double Abe[N * N], Dbe[N * D];
-    {
-      double R[N * N], T[N * N], Den[N * N], X[N * N];
-      rec_load<N * N>(lrec, stride, LRec::R, R);
-      rec_load<N * N>(lrec, stride, LRec::T, T);
-      SS_LOAD_FENCE(); SS_SCHED_FENCE();   // the loads of E, S_dn, S_up stay where they are written (register pressure)
-      // denominator = I - a_above R
-      mat_mul<N, N, N>(Aab, R, Den);
-      SS_UNROLL_NN(N)
-      for (int k = 0; k < N * N; ++k) Den[k] = -Den[k];
-      SS_UNROLL_N(N)
-      for (int j = 0; j < N; ++j) SS_E(Den, j, j, N) = 1.0 + SS_E(Den, j, j, N);
-      lu_factor<N>(Den);
-      // P = Den^-1 T
-      mat_copy<N, N>(T, X);
-      lu_solve_mat<N, N>(Den, X);
-      rec_store<N * N>(crec, stride, CRec::PDN, X);
-      // a_below = R + T Den^-1 (a_above T)
-      mat_mul<N, N, N>(Aab, T, X);
-      lu_solve_mat<N, N>(Den, X);
-      mat_mul<N, N, N>(T, X, Abe);
-      SS_UNROLL_NN(N)
-      for (int k = 0; k < N * N; ++k) Abe[k] = R[k] + Abe[k];
-      rec_store<N * N>(crec, stride, CRec::ABE, Abe);
-      // d_below = S_up + T Den^-1 (d_above E + a_above S_dn)
-      double E[D * D], S[N * D], Y[N * D];
-      rec_load<D * D>(lrec, stride, LRec::EDIR, E);
-      rec_load<N * D>(lrec, stride, LRec::SDN, S);
-      mat_mul<N, D, D>(Dab, E, Y);
-      {
-        // Q = Den^-1 (R (d_above E) + S_dn)
-        double Q[N * D];
-        mat_mul<N, N, D>(R, Y, Q);
-        SS_UNROLL_FULL
-        for (int k = 0; k < N * D; ++k) Q[k] = Q[k] + S[k];
-        lu_solve_mat<N, D>(Den, Q);
-        rec_store<N * D>(crec, stride, CRec::QDN, Q);
-      }
-      mat_mul_acc<N, N, D>(Aab, S, Y);
-      lu_solve_mat<N, D>(Den, Y);
-      rec_load<N * D>(lrec, stride, LRec::SUP, S);
-      mat_mul<N, N, D>(T, Y, Dbe);
-      SS_UNROLL_FULL
-      for (int k = 0; k < N * D; ++k) Dbe[k] = S[k] + Dbe[k];
-      rec_store<N * D>(crec, stride, CRec::DBE, Dbe);
-    }
-    // overlap to the base of the layer above (forest :495-503, urban :645-653)
-    {
-      double U[NREG * DB], V[DB * NREG];
-      const double* prec = pack_rec(L, jlay, cu, kPackSw);
-      double vf_lo, bf_lo, vf_up = 0.0, bf_up = 0.0;
-      pack_fractions(prec, vf_lo, bf_lo);
-      if (jlay + 1 < nlay) pack_fractions(pack_rec(L, jlay + 1, cu, kPackSw), vf_up, bf_up);
-      interface_overlap_vals<URBAN, false, NREG>(L.cfg.min_vegetation_fraction, jlay + 1 >= nlay, vf_up, bf_up,
-                                                 false, vf_lo, bf_lo, U, V);
-      double roof_a = 0.0, roof_d = 0.0;
-      if (URBAN) {
-        const RecPair ra = rec_pair_load(prec + 8 * kRecStride);   // roof_albedo, roof_albedo_dir
-        roof_a = ra.x;
-        roof_d = cos_sza * ra.y;
-      }
-      // tA = a_below (V (x) I): canopy rows (N x N) and roof rows (NS x N)
-      double tA[N * N], tAroof[NS * N];
-      SS_UNROLL_FULL
-      for (int ju = 0; ju < NREG; ++ju) {
-        SS_UNROLL_FULL
-        for (int s = 0; s < NS; ++s) {
-          const int cc = ju * NS + s;
-          SS_UNROLL_N(N)
-          for (int i = 0; i < N; ++i) {
-            double acc = 0.0;
-            SS_UNROLL_FULL
-            for (int jl = 0; jl < NREG; ++jl) acc += SS_E(Abe, i, jl * NS + s, N) * SS_E(V, jl, ju, DB);
-            SS_E(tA, i, cc, N) = acc;
-          }
-          SS_UNROLL_FULL
-          for (int sr = 0; sr < NS; ++sr)
-            SS_E(tAroof, sr, cc, NS) = URBAN ? (roof_a * lg.hweight[sr]) * SS_E(V, DB - 1, ju, DB) : 0.0;
-        }
-      }
-      apply_U_mat<NREG, DB, NS, N>(U, tA, tAroof, Aab);
-      // tD = d_below V (rect_mat_x_singlemat :462): canopy rows and roof rows
-      double tD[N * D], tDroof[NS * D];
-      SS_UNROLL_FULL
-      for (int ju = 0; ju < NREG; ++ju) {
-        SS_UNROLL_N(N)
-        for (int i = 0; i < N; ++i) {
-          double acc = 0.0;
-          SS_UNROLL_FULL
-          for (int jl = 0; jl < NREG; ++jl) acc += SS_E(Dbe, i, jl, N) * SS_E(V, jl, ju, DB);
-          SS_E(tD, i, ju, N) = acc;
-        }
-        SS_UNROLL_FULL
-        for (int sr = 0; sr < NS; ++sr)
-          SS_E(tDroof, sr, ju, NS) = URBAN ? (roof_d * lg.hweight[sr]) * SS_E(V, DB - 1, ju, DB) : 0.0;
-      }
-      apply_U_mat<NREG, DB, NS, D>(U, tD, tDroof, Dab);
-    }
+    sw_adding_step<N, D>(src, Aab, Dab, crec, Abe, Dbe);
+    sw_overlap_above<URBAN, NREG, NS>(L, cu, jlay, c.nlay, c.cos_sza, Abe, Dbe, Aab, Dab);
   }
+  sw_top_albedos<NREG, NS>(L, c.cidx, c.cos_sza, Aab, Dab);
+}
 
-  // top-of-canopy albedos (forest :520-528, urban :666-674)
-  {
-    double s = 0.0;
-    SS_UNROLL_FULL
-    for (int j1 = 0; j1 < NS; ++j1) {
-      double acc = 0.0;
-      SS_UNROLL_FULL
-      for (int j2 = 0; j2 < NS; ++j2) acc += SS_E(Aab, j1, j2, N) * lg.hweight[j2];
-      s += acc;
+// Layer matrices and adding step of every layer of a column unit on one lane (k_layer_up, see
+// the header of the fused kernels in ss_layer_matrices.hpp)
+template <bool URBAN, int NREG, int NS>
+SS_HD void layer_up_sw(const Launch& L, int cu) {
+  constexpr int N = NREG * NS, D = NREG;
+  using LRec = SwRec<N, D>;
+  using CRec = SwColRec<N, D>;
+  static_assert(CRec::FUSED && LRec::SUP <= kLaneLdsSlots, "fused form needs R and T in the lane's LDS slots");
+  using Lds = LaneLds<true>;
+  constexpr long stride = kRecStride;
+  const Inputs& in = L.in;
+  const SwColCtx<URBAN, NREG, NS> c(L, cu, false);
+  const Lds lds{};
+  for (int jlay = 0; jlay < c.nlay; ++jlay) {
+    double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
+    // layer stage: R, T -> LDS; S_up, S_dn, E -> registers; E, int_dir -> column record
+#if defined(SS_FUSE_VIA_RECORD)
+    double hold[2];
+    const FusedWriter<LRec::SUP, LRec::SUP, LRec::SUP, CRec::TAIL, Lds> w{
+        &lds, hold, crec, stride, (unsigned long long*)L.eigen_fail};
+#else
+    double hold[LRec::IDIR - LRec::SUP];
+    const FusedWriter<LRec::SUP, LRec::IDIR, LRec::EDIR, CRec::EDIR, Lds> w{
+        &lds, hold, crec, stride, (unsigned long long*)L.eigen_fail};
+#endif
+    layer_unit_sw<URBAN, NREG, NS>(L, cu, jlay, w);
+    // a_above, d_above: from the ground, or from a_below / d_below of the layer below (written a
+    // layer ago) through the overlap matrices of the interface in between
+    double Aab[N * N], Dab[N * D];
+    if (jlay == 0) {
+      sw_ground_albedo<NREG, NS>(L.lg, in.ground_albedo[c.cidx], in.ground_albedo_dir[c.cidx], c.cos_sza, Aab, Dab);
+    } else {
+      const double* prev = L.col + rec_base(jlay - 1, L.maxlay, CRec::NELEM, cu);
+      double Abe[N * N], Dbe[N * D];
+      rec_load<N * N>(prev, stride, CRec::ABE, Abe);
+      rec_load<N * D>(prev, stride, CRec::DBE, Dbe);
+      sw_overlap_above<URBAN, NREG, NS>(L, cu, jlay - 1, c.nlay, c.cos_sza, Abe, Dbe, Aab, Dab);
     }
-    L.top1[cidx] = s;
-    s = 0.0;
-    SS_UNROLL_FULL
-    for (int j1 = 0; j1 < NS; ++j1) s += SS_E(Dab, j1, 0, N);
-    L.top2[cidx] = s / cos_sza;
+#if defined(SS_FUSE_VIA_RECORD)
+    const LdsRecSource<LRec::SUP, CRec::TAIL, Lds> src{&lds, crec, stride};
+#else
+    const FusedSource<LRec::SUP, Lds> src{&lds, hold};
+#endif
+    double Abe[N * N], Dbe[N * D];
+    sw_adding_step<N, D>(src, Aab, Dab, crec, Abe, Dbe);
+  }
+  if (c.nlay > 0) {
+    const double* prev = L.col + rec_base(c.nlay - 1, L.maxlay, CRec::NELEM, cu);
+    double Abe[N * N], Dbe[N * D], Aab[N * N], Dab[N * D];
+    rec_load<N * N>(prev, stride, CRec::ABE, Abe);
+    rec_load<N * D>(prev, stride, CRec::DBE, Dbe);
+    sw_overlap_above<URBAN, NREG, NS>(L, cu, c.nlay - 1, c.nlay, c.cos_sza, Abe, Dbe, Aab, Dab);
+    sw_top_albedos<NREG, NS>(L, c.cidx, c.cos_sza, Aab, Dab);
   }
 }
 
@@ -410,7 +496,8 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
 
     // ---- issue group 2 (E, Q), work on the fluxes just below the top interface ----
     double E[D * D], Q[N * D];
-    rec_load<D * D>(lrec, st, LRec::EDIR, E);
+    if (CRec::FUSED) rec_load<D * D>(crec, st, CRec::EDIR, E);
+    else rec_load<D * D>(lrec, st, LRec::EDIR, E);
     rec_load<N * D>(crec, st, CRec::QDN, Q);
     SS_LOAD_FENCE();
 
@@ -464,7 +551,8 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
       rec_load<N * N>(crec_n, st, CRec::ABE, ABE);
       rec_load<N * D>(crec_n, st, CRec::DBE, DBE);
     }
-    rec_load<D * D>(lrec, st, LRec::IDIR, IDIR);
+    if (CRec::FUSED) rec_load<D * D>(crec, st, CRec::IDIR, IDIR);
+    else rec_load<D * D>(lrec, st, LRec::IDIR, IDIR);
     SS_LOAD_FENCE();
 
     // flux at the base of the layer: diff = P diff_top + Q dir_top
@@ -672,7 +760,8 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
 // Whole column on one lane (host emulation and small problems)
 template <bool URBAN, int NREG, int NS>
 SS_HD void column_unit_sw(const Launch& L, int cu) {
-  column_up_sw<URBAN, NREG, NS>(L, cu);
+  if constexpr (SwColRec<NREG * NS, NREG>::FUSED) layer_up_sw<URBAN, NREG, NS>(L, cu);
+  else column_up_sw<URBAN, NREG, NS>(L, cu);
   column_down_sw<URBAN, NREG, NS>(L, cu, 0);
   column_down_sw<URBAN, NREG, NS>(L, cu, 1);
 }

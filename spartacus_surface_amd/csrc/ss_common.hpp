@@ -69,8 +69,8 @@ struct LaneLds {
   SS_HD void put(int slot, double v) const { p[slot * 64] = v; }
   SS_HD double get(int slot) const { return p[slot * 64]; }
 #else
-  double a[kLaneLdsSlots];
-  SS_HD void put(int slot, double v) { a[slot] = v; }
+  mutable double a[kLaneLdsSlots] = {};
+  SS_HD void put(int slot, double v) const { a[slot] = v; }
   SS_HD double get(int slot) const { return a[slot]; }
 #endif
 };

@@ -48,6 +48,17 @@ __global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_LAYER)) k
   else layer_unit_sw<U, R, NS>(L, cu, jlay);
 }
 
+// layer matrices + upward sweep of a column unit on one lane (orders that live in registers)
+template <bool U, int R, int NS, bool LW>
+__global__ void __launch_bounds__(kBlock, 1) k_layer_up(const Launch L) {
+  const int cu = blockIdx.x * kBlock + threadIdx.x;
+  if (cu >= L.ncu) return;
+  if constexpr (fused_order(R * NS, LW)) {
+    if constexpr (LW) layer_up_lw<U, R, NS>(L, cu);
+    else layer_up_sw<U, R, NS>(L, cu);
+  }
+}
+
 // upward sweep (adding method)
 template <bool U, int R, int NS, bool LW>
 __global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_COLUMN)) k_column(const Launch L) {
@@ -74,13 +85,27 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev) {
   {
     // the plan sized the scratch with its own formula: it must match the records
     constexpr int N = SS_INST_NREG * NS, D = SS_INST_NREG;
-    constexpr int lay_ne = SS_INST_LW ? LwRec<N>::NELEM : SwRec<N, D>::NELEM;
+    constexpr int lay_ne = fused_order(N, SS_INST_LW != 0) ? 0 : (SS_INST_LW ? LwRec<N>::NELEM : SwRec<N, D>::NELEM);
     constexpr int col_ne = SS_INST_LW ? LwColRec<N>::NELEM : SwColRec<N, D>::NELEM;
     if (L.lay_nelem != lay_ne || L.col_nelem != col_ne) return kLaunchBadRecord;
   }
   if (L.ncu <= 0 || L.maxlay <= 0) return 0;
   const unsigned gx = (unsigned)((L.ncu + kBlock - 1) / kBlock);
   if (ev) SS_TRY(hipEventRecord(ev[0], stream));
+  if constexpr (fused_order(SS_INST_NREG * NS, SS_INST_LW != 0)) {
+    // fused form: one kernel for the layer matrices and the upward sweep (the "column" span is empty)
+    hipLaunchKernelGGL((k_layer_up<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx), dim3(kBlock), 0,
+                       stream, L);
+    SS_TRY(hipGetLastError());
+    if (ev) SS_TRY(hipEventRecord(ev[1], stream));
+    if (ev) SS_TRY(hipEventRecord(ev[2], stream));
+    const unsigned gd = (unsigned)((2L * L.ncu + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((k_down<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gd), dim3(kBlock), 0,
+                       stream, L);
+    SS_TRY(hipGetLastError());
+    if (ev) SS_TRY(hipEventRecord(ev[3], stream));
+    return 0;
+  }
 #ifndef SS_LAYER_GRID_2D
   const dim3 glayer(((gx + 7) / 8) * 8 * (unsigned)L.maxlay);
 #else

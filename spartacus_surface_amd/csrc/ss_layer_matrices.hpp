@@ -147,10 +147,103 @@ struct RecWriter {
   }
 };
 
+// ---- fused layer + upward-sweep kernels (orders that live in registers) ----
+// The layer kernel used to hand its matrices to the upward sweep through an HBM record of
+// 128 (SW) / 120 (LW) doubles per (column, band, layer): written once, read once, 2 x 20 KB per
+// column in the headline configuration - as much traffic as everything else together.  For
+// orders up to SS_UNROLL_MAX one lane now does the layer matrices of a layer AND the adding
+// step that consumes them before it goes on to the next layer (k_layer_up): R and T wait in the
+// lane's LDS slots (2 n^2 <= 72 of kLaneLdsSlots = 80 doubles), the direct-beam / source
+// blocks in registers, and what only the downward sweep reads (E, int_dir; int_flux, int_source)
+// goes straight into the column record.  The loop-carried albedo matrices are not kept across
+// the layer stage (they would be spilled): the adding step re-reads a_below / d_below of the
+// layer below, which it wrote to the column record a layer earlier (L2), and applies the
+// overlap matrices first.  -DSS_NO_FUSE builds the three-kernel form for every order.
+// Measured on C3, 1e6 columns, one stream (ms per step; tools/run_variants.sh):
+//                      layer+up SW   layer+up LW   4 streams, columns/s
+//   three kernels      6.3 + 4.1     6.3 + 3.2     42.4e6
+//   fused, both        11.5 (10.8 with S_up/S_dn through the record, -DSS_FUSE_VIA_RECORD)
+//                                    9.4           40.1e6
+//   fused, LW only     6.3 + 4.1     9.4           42.7e6     <- the default
+// The fused kernel is the sum of its parts, not less: with one wave per SIMD the adding step
+// was bound by exposed latencies, not by the bytes of the layer record, and the shortwave form
+// spills three times as much as its two halves (831 against 270 + 94 dwords).  The longwave
+// form costs nothing and takes 20 KB per column off the HBM traffic, so it is on; the
+// shortwave form stays available (-DSS_FUSE_SW) and correct (all parity tests pass with it).
+constexpr bool fused_order(int n, bool lw) {
+#if defined(SS_NO_FUSE)
+  return false && n > 0 && lw;
+#elif defined(SS_FUSE_SW)
+  return n <= SS_UNROLL_MAX || (false && lw);
+#else
+  return lw && n <= SS_UNROLL_MAX;
+#endif
+}
+
+// Writer of the fused layer stage: elements below KEEP0 (R, T) go to the lane's LDS slots,
+// [KEEP0, KEEP1) stay in registers (hold), [FWD0, ...) are stored to the column record at
+// element FWD_AT + (e - FWD0); an element range may be both kept and forwarded.
+template <int KEEP0, int KEEP1, int FWD0, int FWD_AT, class Lds>
+struct FusedWriter {
+  const Lds* lds;
+  double* hold;           // KEEP1 - KEEP0 elements
+  double* crec;           // column record of this (unit, layer)
+  long stride;
+  unsigned long long* stamps;
+  SS_HD void put2(int e, double v0, double v1) const {
+    if (e < KEEP0) {
+      lds->put(e, v0);
+      lds->put(e + 1, v1);
+    } else {
+      if (e < KEEP1) {
+        hold[e - KEEP0] = v0;
+        hold[e + 1 - KEEP0] = v1;
+      }
+      if (e >= FWD0) rec_pair_store(crec + (long)(FWD_AT + e - FWD0) * stride, v0, v1);
+    }
+  }
+};
+
+// Sources of the adding step: the HBM layer record (three-kernel form) ...
+struct RecSource {
+  const double* rec;
+  long stride;
+  template <int NEL>
+  SS_HD void load(int off, double* dst) const { rec_load<NEL>(rec, stride, off, dst); }
+};
+// ... or what the fused layer stage left in LDS / registers
+template <int KEEP0, class Lds>
+struct FusedSource {
+  const Lds* lds;
+  const double* hold;
+  template <int NEL>
+  SS_HD void load(int off, double* dst) const {
+    SS_UNROLL_FULL
+    for (int k = 0; k < NEL; ++k) dst[k] = (off < KEEP0) ? lds->get(off + k) : hold[off + k - KEEP0];
+  }
+};
+
+// ... or LDS for the elements below KEEP0 and a record (element e at AT + e - KEEP0) for the rest
+template <int KEEP0, int AT, class Lds>
+struct LdsRecSource {
+  const Lds* lds;
+  const double* rec;
+  long stride;
+  template <int NEL>
+  SS_HD void load(int off, double* dst) const {
+    if (off < KEEP0) {
+      SS_UNROLL_FULL
+      for (int k = 0; k < NEL; ++k) dst[k] = lds->get(off + k);
+    } else {
+      rec_load<NEL>(rec, stride, AT + off - KEEP0, dst);
+    }
+  }
+};
+
 // Write an (RS x CS) block held in registers into the (RF x CF) matrix that
 // starts at the even element "off", at block position (I0, J0); everything else zero.
-template <int RF, int CF, int RS, int CS, int I0, int J0>
-SS_HD void put_embedded(const RecWriter& w, int off, const double* blk) {
+template <int RF, int CF, int RS, int CS, int I0, int J0, class W>
+SS_HD void put_embedded(const W& w, int off, const double* blk) {
   auto val = [&](int idx) -> double {
     const int i = idx % RF, j = idx / RF;
     const bool inside = (idx < RF * CF) && (i >= I0) && (i < I0 + RS) && (j >= J0) && (j < J0 + CS);
@@ -160,8 +253,8 @@ SS_HD void put_embedded(const RecWriter& w, int off, const double* blk) {
   for (int e = 0; e < RF * CF; e += 2) w.put2(off + e, val(e), val(e + 1));
 }
 // Same for a vector of NF elements holding an N-vector at I0
-template <int NF, int N, int I0, typename F>
-SS_HD void put_embedded_vec(const RecWriter& w, int off, F&& elem) {
+template <int NF, int N, int I0, class W, typename F>
+SS_HD void put_embedded_vec(const W& w, int off, F&& elem) {
   auto val = [&](int i) -> double {
     const bool inside = (i < NF) && (i >= I0) && (i < I0 + N);
     return inside ? elem(i - I0) : 0.0;
@@ -333,10 +426,10 @@ SS_HD int diffuse_part(const double* g1, const double* g2, const double* dscale,
 
 // calc_matrices_sw_eig for an (N, D) sub-problem embedded at (I0 = stream
 // offset, R0 = region offset) of the full (NF, DF) record.
-template <int NF, int DF, int N, int D, int I0, int R0>
+template <int NF, int DF, int N, int D, int I0, int R0, class W>
 SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
                            const double* g3, const double* dsc0, const double* dsc, double dz,
-                           const RecWriter& w) {
+                           const W& w) {
   using Rec = SwRec<NF, DF>;
   SS_STAMP_DECL(w.stamps);
   int ierr = 0;
@@ -458,9 +551,9 @@ SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
 }
 
 // calc_matrices_lw_eig for an N sub-problem embedded at stream offset I0.
-template <int NF, int N, int I0>
+template <int NF, int N, int I0, class W>
 SS_HD int calc_matrices_lw(const double* g1, const double* g2, const double* b, const double* dsc,
-                           double dz, const RecWriter& w) {
+                           double dz, const W& w) {
   using Rec = LwRec<NF>;
   SS_STAMP_DECL(w.stamps);
   // Section 3 (:178-195): inv_gamma_b (first, while only the Gamma matrices are live)

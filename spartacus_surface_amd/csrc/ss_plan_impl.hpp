@@ -71,8 +71,11 @@ inline bool key_supported(const ClassKey& k) {
 }
 
 // Number of scratch elements per layer of a class
+// (orders of the fused layer + upward kernel have no layer record, and their column record
+// also carries what the downward sweep used to read from it: fused_order, ss_layer_matrices.hpp)
 inline int lay_nelem(bool lw, const ClassKey& k) {
   const int n = k.nreg * k.ns, d = k.nreg;
+  if (fused_order(n, lw)) return 0;
   auto ev = [](int x) { return (x + 1) & ~1; };   // blocks start at even elements (16-byte pairs)
   return lw ? 3 * ev(n * n) + 2 * ev(n) : 2 * ev(n * n) + 2 * ev(n * d) + 2 * ev(d * d);
 }
@@ -80,7 +83,13 @@ inline int col_nelem(bool lw, const ClassKey& k) {
   const int n = k.nreg * k.ns, d = k.nreg;
   // = LwColRec<n>::NELEM / SwColRec<n,d>::NELEM (ss_column_lw.hpp, ss_column_sw.hpp)
   auto ev = [](int x) { return (x + 1) & ~1; };
-  return lw ? 2 * ev(n * n) + 2 * ev(n) : 2 * ev(n * n) + 2 * ev(n * d);
+  const int base = lw ? 2 * ev(n * n) + 2 * ev(n) : 2 * ev(n * n) + 2 * ev(n * d);
+  if (!fused_order(n, lw)) return base;
+#if defined(SS_FUSE_VIA_RECORD)
+  return base + (lw ? ev(n * n) + ev(n) : 2 * ev(d * d) + 2 * ev(n * d));
+#else
+  return base + (lw ? ev(n * n) + ev(n) : 2 * ev(d * d));
+#endif
 }
 
 // Runtime (urban, nreg, ns) -> template instance

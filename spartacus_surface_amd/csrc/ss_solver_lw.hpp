@@ -98,11 +98,11 @@ SS_HD void lw_layer_props(const Launch& L, int lay, long sidx, LwLayerProps<URBA
   lw_layer_props<URBAN, NREG>(L, r, p);
 }
 
-template <bool URBAN, int NREG, int NS>
-SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay) {
+// W: RecWriter (HBM layer record) or the FusedWriter of k_layer_up (ss_layer_matrices.hpp)
+template <bool URBAN, int NREG, int NS, class W>
+SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
   SS_STAMP_DECL((unsigned long long*)L.eigen_fail);
   constexpr int N = NREG * NS;
-  using Rec = LwRec<N>;
   const Inputs& in = L.in;
   const LG& lg = L.lg;
   const int col = L.cols[cu / L.nspec];
@@ -195,7 +195,6 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay) {
     for (int js = 0; js < NS; ++js) dsc[js + r * NS] = dr * lg.sqrt_wmu[js];
   }
 
-  RecWriter w{L.lay + rec_base(jlay, L.maxlay, Rec::NELEM, cu), kRecStride, (unsigned long long*)L.eigen_fail};
   SS_STAMP(10);
   int ierr;
   if (NREG == 1 || p.g.veg_fraction <= L.cfg.min_vegetation_fraction) {
@@ -218,6 +217,13 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay) {
 #else
   if (ierr != 0 && L.eigen_fail) *L.eigen_fail += 1ULL;
 #endif
+}
+
+template <bool URBAN, int NREG, int NS>
+SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay) {
+  using Rec = LwRec<NREG * NS>;
+  const RecWriter w{L.lay + rec_base(jlay, L.maxlay, Rec::NELEM, cu), kRecStride, (unsigned long long*)L.eigen_fail};
+  layer_unit_lw<URBAN, NREG, NS>(L, cu, jlay, w);
 }
 
 }  // namespace ss

@@ -51,11 +51,12 @@ SS_HD void region_optics(double air_ext, double air_ssa, double veg_ext, double 
   }
 }
 
-template <bool URBAN, int NREG, int NS>
-SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay) {
+// W: where the layer matrices go - RecWriter (HBM layer record, three-kernel form) or the
+// FusedWriter of k_layer_up (LDS / registers / column record)
+template <bool URBAN, int NREG, int NS, class W>
+SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
   SS_STAMP_DECL((unsigned long long*)L.eigen_fail);
   constexpr int N = NREG * NS, D = NREG;
-  using Rec = SwRec<N, D>;
   const Inputs& in = L.in;
   const int col = L.cols[cu / L.nspec];
   const int jb = cu % L.nspec;
@@ -177,7 +178,6 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay) {
   }
 
   // ---- layer matrices, 3-way branch (forest :408-455, urban :520-583) ----
-  RecWriter w{L.lay + rec_base(jlay, L.maxlay, Rec::NELEM, cu), kRecStride, (unsigned long long*)L.eigen_fail};
   SS_STAMP(0);
   int ierr;
   if (NREG == 1 || g.veg_fraction <= L.cfg.min_vegetation_fraction) {
@@ -208,6 +208,13 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay) {
 #else
   if (ierr != 0 && L.eigen_fail) *L.eigen_fail += 1ULL;
 #endif
+}
+
+template <bool URBAN, int NREG, int NS>
+SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay) {
+  using Rec = SwRec<NREG * NS, NREG>;
+  const RecWriter w{L.lay + rec_base(jlay, L.maxlay, Rec::NELEM, cu), kRecStride, (unsigned long long*)L.eigen_fail};
+  layer_unit_sw<URBAN, NREG, NS>(L, cu, jlay, w);
 }
 
 // Gamma1 + Gamma2 (B, N x N) and Gamma3 (g3, N x D) of one layer from its inputs, as

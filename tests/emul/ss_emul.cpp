@@ -58,11 +58,13 @@ struct EmulBackend {
   }
   template <bool U, int R, int NS>
   static void run(bool lw, const ss::Launch& L) {
-    for (int jlay = 0; jlay < L.maxlay; ++jlay)
-      for (int cu = 0; cu < L.ncu; ++cu) {
-        if (lw) ss::layer_unit_lw<U, R, NS>(L, cu, jlay);
-        else ss::layer_unit_sw<U, R, NS>(L, cu, jlay);
-      }
+    // orders of the fused kernel do the layer matrices inside column_unit_* (layer_up_*)
+    if (!ss::fused_order(R * NS, lw))
+      for (int jlay = 0; jlay < L.maxlay; ++jlay)
+        for (int cu = 0; cu < L.ncu; ++cu) {
+          if (lw) ss::layer_unit_lw<U, R, NS>(L, cu, jlay);
+          else ss::layer_unit_sw<U, R, NS>(L, cu, jlay);
+        }
     for (int cu = 0; cu < L.ncu; ++cu) {
       if (lw) ss::column_unit_lw<U, R, NS>(L, cu);
       else ss::column_unit_sw<U, R, NS>(L, cu);

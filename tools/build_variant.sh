@@ -8,8 +8,9 @@ OD="${TMPDIR:-/tmp}/ss_variants/$NAME"; mkdir -p $OD ../lib/variants
 for u in inst_sw_urban_r3 inst_lw_urban_r3; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-cuda-compat -DSS_ONLY_NS=$NSV $FLAGS -c $u.hip -o $OD/$u.o &
 done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-cuda-compat $FLAGS -c ss_capi.hip -o $OD/ss_capi.o &
 wait
-OBJS=""; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-cuda-compat $FLAGS -c ss_capi.hip -o $OD/ss_capi.o; OBJS="$OD/ss_capi.o"
+OBJS="$OD/ss_capi.o ../lib/obj/ss_units_capi.o"
 for u in inst_sw_forest_r2 inst_sw_forest_r3 inst_sw_urban_r1 inst_sw_urban_r2 inst_lw_forest_r2 inst_lw_forest_r3 inst_lw_urban_r1 inst_lw_urban_r2; do OBJS="$OBJS ../lib/obj/$u.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/libss_$NAME.so $OBJS $OD/inst_sw_urban_r3.o $OD/inst_lw_urban_r3.o
 echo built $NAME
