@@ -175,6 +175,8 @@ struct Launch {
   int lay_nelem, col_nelem;   // record sizes the plan sized the scratch for (checked at launch)
   double* lay;           // layer-matrix scratch  [tile][layer][elem pair][lane][2]
   double* col;           // adding-method scratch, same tiling
+  double* eig;           // eigen records of the cooperative eigen-solver (ss_eigen_coop.hpp), same tiling
+  int eig_nelem;
   // Per-layer inputs of the class, re-laid out once per upload in the tiling of the
   // scratch records (ss_pack.hpp): unit cu of this launch is unit pack_cu0 + cu of the pack
   const double* pack;

@@ -28,7 +28,7 @@ namespace {
 #define SS_MIN_WAVES_DOWN 1
 #endif
 
-template <bool U, int R, int NS, bool LW>
+template <bool U, int R, int NS, bool LW, int STAGE = 0>
 __global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_LAYER)) k_layer(const Launch L) {
 #ifndef SS_LAYER_GRID_2D
   // Block -> (tile of 64 column units, layer).  The per-layer inputs of a column
@@ -44,8 +44,22 @@ __global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_LAYER)) k
 #endif
   const int cu = tile * kBlock + threadIdx.x;
   if (cu >= L.ncu) return;
-  if (LW) layer_unit_lw<U, R, NS>(L, cu, jlay);
-  else layer_unit_sw<U, R, NS>(L, cu, jlay);
+  if (LW) layer_unit_lw<U, R, NS, STAGE>(L, cu, jlay);
+  else layer_unit_sw<U, R, NS, STAGE>(L, cu, jlay);
+}
+
+// cooperative eigen-solver between the two passes of the layer kernel (ss_eigen_coop.hpp):
+// block -> (tile of 64 units, layer, quarter of the tile); 4 lanes per unit, 16 units per wave
+template <int N>
+__global__ void __launch_bounds__(kBlock, 2) k_eig_coop(const Launch L) {
+  const int quarter = blockIdx.x & 3, tl = blockIdx.x >> 2;
+  const int tile = tl / L.maxlay, jlay = tl % L.maxlay;
+  const int cu = tile * kBlock + quarter * 16 + ((int)threadIdx.x >> 2);
+  if (cu >= L.ncu) return;
+  if (jlay >= L.in.nlay[L.cols[cu / L.nspec]]) return;
+  if constexpr (coop_order(N))
+    coop_eig_unit<N, kCoopLanes>(L.eig + rec_base(jlay, L.maxlay, EigRec<N>::NELEM, cu), kRecStride,
+                                 (int)threadIdx.x & 3);
 }
 
 // layer matrices + upward sweep of a column unit on one lane (orders that live in registers)
@@ -111,9 +125,22 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev) {
 #else
   const dim3 glayer(gx, (unsigned)L.maxlay);
 #endif
-  hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), glayer, dim3(kBlock), 0,
-                     stream, L);
-  SS_TRY(hipGetLastError());
+  if constexpr (coop_order(SS_INST_NREG * NS)) {
+    // W of every full problem -> cooperative Jacobi -> layer matrices with the eigen-decomposition from the record
+    if (L.eig_nelem != EigRec<SS_INST_NREG * NS>::NELEM || !L.eig) return kLaunchBadRecord;
+    hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0, 1>), glayer, dim3(kBlock), 0,
+                       stream, L);
+    SS_TRY(hipGetLastError());
+    hipLaunchKernelGGL((k_eig_coop<SS_INST_NREG * NS>), dim3(gx * (unsigned)L.maxlay * 4), dim3(kBlock), 0, stream, L);
+    SS_TRY(hipGetLastError());
+    hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0, 2>), glayer, dim3(kBlock), 0,
+                       stream, L);
+    SS_TRY(hipGetLastError());
+  } else {
+    hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), glayer, dim3(kBlock), 0,
+                       stream, L);
+    SS_TRY(hipGetLastError());
+  }
   if (ev) SS_TRY(hipEventRecord(ev[1], stream));
   hipLaunchKernelGGL((k_column<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx), dim3(kBlock), 0,
                      stream, L);

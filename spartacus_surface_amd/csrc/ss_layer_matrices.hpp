@@ -301,11 +301,21 @@ struct Diffuse {
 // for three matrix-vector products per mu, where the reference factorises two
 // N x N matrices, inverts one and multiplies two per mu.  X^-1 (G1 - G2) s is
 // -(D^-2 X)^T s on the symmetric route and an LU solve with X on the general one.
+// Eigen record of the unit for the orders of the cooperative eigen-solver (ss_eigen_coop.hpp):
+// nullptr = solve here.
+struct CoopEig {
+  const double* rec;
+  long stride;
+};
+template <int N>
+SS_HD int coop_eig_post(const double* A, const double* dscale, const double* rec, long stride,
+                        double* eigenvalue, double* eigenvector, double* ainv_x);
+
 template <int N, int ND = 0, class PutR, class PutT>
 SS_HD int diffuse_part(const double* g1, const double* g2, const double* dscale, double dz, Diffuse<N>& w,
                        const PutR& putR, const PutT& putT, unsigned long long* stamps = nullptr,
                        int stamp0 = 0, const double* srhs = nullptr, const double* mu = nullptr,
-                       double* g3v = nullptr, double* g4v = nullptr) {
+                       double* g3v = nullptr, double* g4v = nullptr, const CoopEig* coop = nullptr) {
   SS_STAMP_DECL(stamps);
   double GD[N * N], P[N * N], X[N * N], ev[N];
   double hc[N * (ND > 0 ? ND : 1)];   // X^-1 (G1 - G2) s, one column per direct eigenvalue
@@ -334,6 +344,19 @@ SS_HD int diffuse_part(const double* g1, const double* g2, const double* dscale,
           hc[k + jd * N] = h;
         }
       }
+    }
+  }
+  if constexpr (N > SS_UNROLL_MAX) {
+    // eigenvalues and vectors solved by the cooperative kernel between the two passes of the layer kernel
+    if (coop && dscale) ierr = coop_eig_post<N>(GD, dscale, coop->rec, coop->stride, ev, X, P);
+    if (ND > 0 && ierr >= 0) {
+      // X^-1 (G1 - G2) s = -(D^-2 X)^T s, as on the symmetric route of the small orders
+      for (int jd = 0; jd < ND; ++jd)
+        for (int k = 0; k < N; ++k) {
+          double h = 0.0;
+          for (int i = 0; i < N; ++i) h -= SS_E(X, i, k, N) * (srhs[i + jd * N] / (dscale[i] * dscale[i]));
+          hc[k + jd * N] = h;
+        }
     }
   }
 #if defined(SS_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
@@ -429,7 +452,7 @@ SS_HD int diffuse_part(const double* g1, const double* g2, const double* dscale,
 template <int NF, int DF, int N, int D, int I0, int R0, class W>
 SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
                            const double* g3, const double* dsc0, const double* dsc, double dz,
-                           const W& w) {
+                           const W& w, const CoopEig* coop = nullptr) {
   using Rec = SwRec<NF, DF>;
   SS_STAMP_DECL(w.stamps);
   int ierr = 0;
@@ -494,7 +517,7 @@ SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
       g1, g2, dsc, dz, df,
       [&](const double* R) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::R, R); },
       [&](const double* T) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::T, T); }, w.stamps, 3,
-      g3g0, mu, g3v, g4v);
+      g3g0, mu, g3v, g4v, coop);
   SS_STAMP(20);   // (re-arm)
 
   // direct_diffuse_part (:303-386) by block elimination (see header comment)
@@ -553,7 +576,7 @@ SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
 // calc_matrices_lw_eig for an N sub-problem embedded at stream offset I0.
 template <int NF, int N, int I0, class W>
 SS_HD int calc_matrices_lw(const double* g1, const double* g2, const double* b, const double* dsc,
-                           double dz, const W& w) {
+                           double dz, const W& w, const CoopEig* coop = nullptr) {
   using Rec = LwRec<NF>;
   SS_STAMP_DECL(w.stamps);
   // Section 3 (:178-195): inv_gamma_b (first, while only the Gamma matrices are live)
@@ -574,7 +597,8 @@ SS_HD int calc_matrices_lw(const double* g1, const double* g2, const double* b, 
   int ierr = diffuse_part<N>(
       g1, g2, dsc, dz, df,
       [&](const double* R) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::R, R); },
-      [&](const double* T) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::T, T); }, w.stamps, 13);
+      [&](const double* T) { put_embedded<NF, NF, N, N, I0, I0>(w, Rec::T, T); }, w.stamps, 13,
+      nullptr, nullptr, nullptr, nullptr, coop);
   SS_STAMP(20);   // (re-arm)
 
   // Section 4 (:198-209): cb' and the source

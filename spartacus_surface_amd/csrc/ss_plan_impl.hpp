@@ -36,6 +36,7 @@
 #include "ss_common.hpp"
 #include "ss_pack.hpp"
 #include "ss_layer_matrices.hpp"
+#include "ss_eigen_coop.hpp"
 #include "ss_misc_units.hpp"
 #include "ss_column_lw.hpp"
 #include "ss_column_sw.hpp"
@@ -90,6 +91,13 @@ inline int col_nelem(bool lw, const ClassKey& k) {
 #else
   return base + (lw ? ev(n * n) + ev(n) : 2 * ev(d * d));
 #endif
+}
+
+// eigen record of the cooperative eigen-solver (= EigRec<n>::NELEM, ss_eigen_coop.hpp); 0 = order not cooperative
+inline int eig_nelem(const ClassKey& k) {
+  const int n = k.nreg * k.ns;
+  auto ev = [](int x) { return (x + 1) & ~1; };
+  return coop_order(n) ? 2 + ev(n) + ev(n * n) : 0;
 }
 
 // Runtime (urban, nreg, ns) -> template instance
@@ -150,11 +158,12 @@ class Plan {
   int npipes = 1;
   double* d_lay[kMaxPipes] = {};
   double* d_col[kMaxPipes] = {};
+  double* d_eig[kMaxPipes] = {};
   size_t scratch_budget_bytes = 0;
   static constexpr int kDefaultPipes = 4;
   int pipes_wanted = kDefaultPipes;
   int pipes_cap = kMaxPipes;     // set before create(): upper limit for this plan
-  size_t lay_bytes = 0, col_bytes = 0;
+  size_t lay_bytes = 0, col_bytes = 0, eig_bytes = 0;
   // slot 0: eigen failures of the last solve; the rest: section stamps of profiling builds
   static constexpr int kCounters = 32;
   unsigned long long* d_eigen_fail = nullptr;
@@ -176,9 +185,10 @@ class Plan {
     for (int p = 0; p < kMaxPipes; ++p) {
       if (d_lay[p]) be.free(d_lay[p]);
       if (d_col[p]) be.free(d_col[p]);
-      d_lay[p] = d_col[p] = nullptr;
+      if (d_eig[p]) be.free(d_eig[p]);
+      d_lay[p] = d_col[p] = d_eig[p] = nullptr;
     }
-    lay_bytes = col_bytes = 0;
+    lay_bytes = col_bytes = eig_bytes = 0;
     if (d_eigen_fail) be.free(d_eigen_fail);
     d_index = nullptr; d_eigen_fail = nullptr;
     timers.release();
@@ -520,7 +530,7 @@ class Plan {
     be.h2d_staged(d_index, idx.data(), idx.size() * sizeof(int32_t));
 
     // scratch sizing: the largest per-column need over all classes
-    size_t need_lay = 0, need_col = 0;
+    size_t need_lay = 0, need_col = 0, need_eig = 0;
     auto account = [&](const std::vector<ColumnClass>& cls, bool lw, int nspec) {
       for (auto& c : cls) {
         const size_t per_unit = (size_t)c.maxlay * sizeof(double);
@@ -528,6 +538,7 @@ class Plan {
         const size_t units = ((chunk * nspec + 63) / 64) * 64;     // whole tiles of 64 units
         need_lay = std::max(need_lay, units * per_unit * lay_nelem(lw, c.key));
         need_col = std::max(need_col, units * per_unit * col_nelem(lw, c.key));
+        need_eig = std::max(need_eig, units * per_unit * eig_nelem(c.key));
       }
     };
     account(sw_classes, false, nsw);
@@ -537,18 +548,21 @@ class Plan {
     for (auto& c : sw_classes) nlaunch += (c.cols.size() + chunk_columns(c, false, nsw) - 1) / chunk_columns(c, false, nsw);
     for (auto& c : lw_classes) nlaunch += (c.cols.size() + chunk_columns(c, true, nlw) - 1) / chunk_columns(c, true, nlw);
     npipes = std::max(1, std::min<int>({kMaxPipes, pipes_wanted, (int)nlaunch}));
-    if (need_lay > lay_bytes || need_col > col_bytes) {
+    if (need_lay > lay_bytes || need_col > col_bytes || need_eig > eig_bytes) {
       for (int p = 0; p < kMaxPipes; ++p) {
         if (d_lay[p]) be.free(d_lay[p]);
         if (d_col[p]) be.free(d_col[p]);
-        d_lay[p] = d_col[p] = nullptr;
+        if (d_eig[p]) be.free(d_eig[p]);
+        d_lay[p] = d_col[p] = d_eig[p] = nullptr;
       }
       lay_bytes = std::max(lay_bytes, need_lay);
       col_bytes = std::max(col_bytes, need_col);
+      eig_bytes = std::max(eig_bytes, need_eig);
     }
     for (int p = 0; p < npipes; ++p) {
       if (!d_lay[p]) d_lay[p] = static_cast<double*>(be.alloc(lay_bytes));
       if (!d_col[p]) d_col[p] = static_cast<double*>(be.alloc(col_bytes));
+      if (!d_eig[p] && eig_bytes) d_eig[p] = static_cast<double*>(be.alloc(eig_bytes));
     }
     return SS_OK;
   }
@@ -560,6 +574,7 @@ class Plan {
       for (int p = npipes; p < pipes_wanted; ++p) {
         if (!d_lay[p]) d_lay[p] = static_cast<double*>(be.alloc(lay_bytes));
         if (!d_col[p]) d_col[p] = static_cast<double*>(be.alloc(col_bytes));
+        if (!d_eig[p] && eig_bytes) d_eig[p] = static_cast<double*>(be.alloc(eig_bytes));
       }
       npipes = pipes_wanted;
     }
@@ -570,7 +585,7 @@ class Plan {
   // within the budget
   size_t chunk_columns(const ColumnClass& c, bool lw, int nspec) const {
     const size_t per_col = (size_t)nspec * c.maxlay * sizeof(double)
-                           * (lay_nelem(lw, c.key) + col_nelem(lw, c.key));
+                           * (lay_nelem(lw, c.key) + col_nelem(lw, c.key) + eig_nelem(c.key));
     size_t chunk = std::max<size_t>(1, scratch_budget_bytes / std::max<size_t>(1, per_col));
     if (chunk >= 128) chunk -= chunk % 64;     // whole waves where possible
     return std::max<size_t>(1, std::min(chunk, c.cols.size()));
@@ -683,6 +698,8 @@ class Plan {
     L.col_nelem = col_nelem(lw, c.key);
     L.lay = d_lay[pipe];
     L.col = d_col[pipe];
+    L.eig = d_eig[pipe];
+    L.eig_nelem = eig_nelem(c.key);
     L.pack = c.d_pack;
     L.pack_maxlay = c.maxlay;
     L.pack_cu0 = (int)(first * (size_t)L.nspec);

@@ -13,6 +13,7 @@
 #include "ss_common.hpp"
 #include "ss_linalg.hpp"
 #include "ss_geometry.hpp"
+#include "ss_eigen_coop.hpp"
 #include "ss_layer_matrices.hpp"
 #include "ss_solver_sw.hpp"
 #include "ss_pack.hpp"
@@ -99,7 +100,8 @@ SS_HD void lw_layer_props(const Launch& L, int lay, long sidx, LwLayerProps<URBA
 }
 
 // W: RecWriter (HBM layer record) or the FusedWriter of k_layer_up (ss_layer_matrices.hpp)
-template <bool URBAN, int NREG, int NS, class W>
+// (STAGE: see layer_unit_sw)
+template <bool URBAN, int NREG, int NS, class W, int STAGE = 0>
 SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
   SS_STAMP_DECL((unsigned long long*)L.eigen_fail);
   constexpr int N = NREG * NS;
@@ -197,6 +199,21 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
 
   SS_STAMP(10);
   int ierr;
+  double* erec = nullptr;
+  if constexpr (STAGE != 0) erec = L.eig + rec_base(jlay, L.maxlay, EigRec<N>::NELEM, cu);
+  if constexpr (STAGE == 1) {
+    const bool full = !(NREG == 1 || p.g.veg_fraction <= L.cfg.min_vegetation_fraction)
+                      && !(p.frac[0] <= L.cfg.min_vegetation_fraction);
+    if (full) {
+      double GD[N * N];
+      for (int k = 0; k < N * N; ++k) GD[k] = g1[k] - g2[k];
+      coop_eig_pre<N>(GD, g2, dsc, erec, kRecStride);
+    } else {
+      rec_pair_store(erec + (long)EigRec<N>::STATUS * kRecStride, 0.0, 0.0);
+    }
+    return;
+  }
+  const CoopEig ce{erec, kRecStride};
   if (NREG == 1 || p.g.veg_fraction <= L.cfg.min_vegetation_fraction) {
     double s1[NS * NS], s2[NS * NS];
     get_block<N, NS, NS, 0, 0>(g1, s1);
@@ -210,7 +227,7 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
     get_block<N, NV, NV, IV, IV>(g2, s2);
     ierr = calc_matrices_lw<N, NV, IV>(s1, s2, b + IV, dsc + IV, p.g.dz, w);
   } else {
-    ierr = calc_matrices_lw<N, N, 0>(g1, g2, b, dsc, p.g.dz, w);
+    ierr = calc_matrices_lw<N, N, 0>(g1, g2, b, dsc, p.g.dz, w, STAGE == 2 ? &ce : nullptr);
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ierr != 0 && L.eigen_fail) atomicAdd(L.eigen_fail, 1ULL);
@@ -219,11 +236,11 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
 #endif
 }
 
-template <bool URBAN, int NREG, int NS>
+template <bool URBAN, int NREG, int NS, int STAGE = 0>
 SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay) {
   using Rec = LwRec<NREG * NS>;
   const RecWriter w{L.lay + rec_base(jlay, L.maxlay, Rec::NELEM, cu), kRecStride, (unsigned long long*)L.eigen_fail};
-  layer_unit_lw<URBAN, NREG, NS>(L, cu, jlay, w);
+  layer_unit_lw<URBAN, NREG, NS, RecWriter, STAGE>(L, cu, jlay, w);
 }
 
 }  // namespace ss

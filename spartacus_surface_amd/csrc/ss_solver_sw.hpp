@@ -18,6 +18,7 @@
 #include "ss_linalg.hpp"
 #include "ss_geometry.hpp"
 #include "ss_layer_matrices.hpp"
+#include "ss_eigen_coop.hpp"
 #include "ss_pack.hpp"
 
 namespace ss {
@@ -52,8 +53,11 @@ SS_HD void region_optics(double air_ext, double air_ssa, double veg_ext, double 
 }
 
 // W: where the layer matrices go - RecWriter (HBM layer record, three-kernel form) or the
-// FusedWriter of k_layer_up (LDS / registers / column record)
-template <bool URBAN, int NREG, int NS, class W>
+// FusedWriter of k_layer_up (LDS / registers / column record).
+// STAGE (orders of the cooperative eigen-solver, ss_eigen_coop.hpp): 0 = everything here;
+// 1 = first pass: only the factor W of the full problem goes to the eigen record;
+// 2 = second pass: everything, with the eigen-decomposition taken from the record.
+template <bool URBAN, int NREG, int NS, class W, int STAGE = 0>
 SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
   SS_STAMP_DECL((unsigned long long*)L.eigen_fail);
   constexpr int N = NREG * NS, D = NREG;
@@ -180,6 +184,21 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
   // ---- layer matrices, 3-way branch (forest :408-455, urban :520-583) ----
   SS_STAMP(0);
   int ierr;
+  double* erec = nullptr;
+  if constexpr (STAGE != 0) erec = L.eig + rec_base(jlay, L.maxlay, EigRec<N>::NELEM, cu);
+  if constexpr (STAGE == 1) {
+    const bool full = !(NREG == 1 || g.veg_fraction <= L.cfg.min_vegetation_fraction)
+                      && !(frac[0] <= L.cfg.min_vegetation_fraction);
+    if (full) {
+      double GD[N * N];
+      for (int k = 0; k < N * N; ++k) GD[k] = g1[k] - g2[k];
+      coop_eig_pre<N>(GD, g2, dsc, erec, kRecStride);
+    } else {
+      rec_pair_store(erec + (long)EigRec<N>::STATUS * kRecStride, 0.0, 0.0);
+    }
+    return;
+  }
+  const CoopEig ce{erec, kRecStride};
   if (NREG == 1 || g.veg_fraction <= L.cfg.min_vegetation_fraction) {
     // clear-sky region only: (1:ns, 1:1)
     double s0[1], s1[NS * NS], s2[NS * NS], s3[NS];
@@ -201,7 +220,7 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
     get_block<N, NV, DV, IV, RV>(g3, s3);
     ierr = calc_matrices_sw<N, D, NV, DV, IV, RV>(s0, s1, s2, s3, dsc0 + RV, dsc + IV, g.dz, w);
   } else {
-    ierr = calc_matrices_sw<N, D, N, D, 0, 0>(g0, g1, g2, g3, dsc0, dsc, g.dz, w);
+    ierr = calc_matrices_sw<N, D, N, D, 0, 0>(g0, g1, g2, g3, dsc0, dsc, g.dz, w, STAGE == 2 ? &ce : nullptr);
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ierr != 0 && L.eigen_fail) atomicAdd(L.eigen_fail, 1ULL);
@@ -210,11 +229,11 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
 #endif
 }
 
-template <bool URBAN, int NREG, int NS>
+template <bool URBAN, int NREG, int NS, int STAGE = 0>
 SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay) {
   using Rec = SwRec<NREG * NS, NREG>;
   const RecWriter w{L.lay + rec_base(jlay, L.maxlay, Rec::NELEM, cu), kRecStride, (unsigned long long*)L.eigen_fail};
-  layer_unit_sw<URBAN, NREG, NS>(L, cu, jlay, w);
+  layer_unit_sw<URBAN, NREG, NS, RecWriter, STAGE>(L, cu, jlay, w);
 }
 
 // Gamma1 + Gamma2 (B, N x N) and Gamma3 (g3, N x D) of one layer from its inputs, as

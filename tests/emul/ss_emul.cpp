@@ -59,12 +59,26 @@ struct EmulBackend {
   template <bool U, int R, int NS>
   static void run(bool lw, const ss::Launch& L) {
     // orders of the fused kernel do the layer matrices inside column_unit_* (layer_up_*)
-    if (!ss::fused_order(R * NS, lw))
+    if (!ss::fused_order(R * NS, lw)) {
+      constexpr bool coop = ss::coop_order(R * NS);
+      constexpr int NN = R * NS;
+      if constexpr (coop) {
+        // the two passes of the layer kernel around the cooperative eigen-solver, which a host
+        // build runs with one "lane" per problem (same arithmetic, no lanes to share the rows with)
+        for (int jlay = 0; jlay < L.maxlay; ++jlay)
+          for (int cu = 0; cu < L.ncu; ++cu) {
+            if (lw) ss::layer_unit_lw<U, R, NS, 1>(L, cu, jlay);
+            else ss::layer_unit_sw<U, R, NS, 1>(L, cu, jlay);
+            if (jlay < L.in.nlay[L.cols[cu / L.nspec]])
+              ss::coop_eig_unit<NN, 1>(L.eig + ss::rec_base(jlay, L.maxlay, ss::EigRec<NN>::NELEM, cu), ss::kRecStride, 0);
+          }
+      }
       for (int jlay = 0; jlay < L.maxlay; ++jlay)
         for (int cu = 0; cu < L.ncu; ++cu) {
-          if (lw) ss::layer_unit_lw<U, R, NS>(L, cu, jlay);
-          else ss::layer_unit_sw<U, R, NS>(L, cu, jlay);
+          if (lw) ss::layer_unit_lw<U, R, NS, coop ? 2 : 0>(L, cu, jlay);
+          else ss::layer_unit_sw<U, R, NS, coop ? 2 : 0>(L, cu, jlay);
         }
+    }
     for (int cu = 0; cu < L.ncu; ++cu) {
       if (lw) ss::column_unit_lw<U, R, NS>(L, cu);
       else ss::column_unit_sw<U, R, NS>(L, cu);
