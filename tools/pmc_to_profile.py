@@ -29,7 +29,15 @@ def newest_per_pass(root):
 tag, ncol = sys.argv[1], int(sys.argv[2])
 FAMILY = {("k_layer", "false"): "sw_layer", ("k_column", "false"): "sw_column",
           ("k_down", "false"): "sw_down", ("k_down", "true"): "lw_down",
-          ("k_layer", "true"): "lw_layer", ("k_column", "true"): "lw_column"}
+          ("k_layer", "true"): "lw_layer", ("k_column", "true"): "lw_column",
+          # the fused layer + upward kernel is timed as the "layer" family of its spectral region
+          ("k_layer_up", "false"): "sw_layer", ("k_layer_up", "true"): "lw_layer"}
+
+
+def family_of(kernel, args):
+    # template arguments: <URBAN, NREG, NS, LW[, STAGE]>
+    a = [x.strip() for x in args.split(",")]
+    return FAMILY.get((kernel, a[3] if len(a) > 3 else ""), kernel)
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 meta = {}
 for f in newest_per_pass("gpurun_out/pmc_%s" % tag):
@@ -41,7 +49,7 @@ for f in newest_per_pass("gpurun_out/pmc_%s" % tag):
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         meta[k] = {"vgpr": int(r["VGPR_Count"]), "agpr": int(r["Accum_VGPR_Count"]),
                    "sgpr": int(r["SGPR_Count"]), "scratch_bytes_per_lane": int(r["Scratch_Size"]),
-                   "family": FAMILY.get((m.group(1), m.group(2).split(",")[-1].strip()), m.group(1))}
+                   "family": family_of(m.group(1), m.group(2))}
 out = {"command": "rocprofv3 --pmc <one group per pass> -- python bench.py --steps 1 --warmup 0 "
                   "--columns %d --no-cpu-baseline (tools/profile_round.sh)" % ncol,
        "columns": ncol, "kernels": {}}

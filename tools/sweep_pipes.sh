@@ -1,7 +1,8 @@
 #!/bin/bash
-# usage: sweep_pipes.sh "pipes list" [bench args...]: throughput against the number of HIP streams (scratch budget per stream scaled to keep the total)
-for p in $1; do
-  mb=$((16384 / p)); [ $mb -gt 4096 ] && mb=4096
-  echo "== SPARTACUS_PIPES=$p SPARTACUS_SCRATCH_MB=$mb"
-  SPARTACUS_PIPES=$p SPARTACUS_SCRATCH_MB=$mb bash tools/quick_bench.sh --no-extras "${@:2}" || exit 1
+# usage (GPU box): sweep_pipes.sh -> columns/s of the default bench for streams x scratch budget
+for mb in 1024 4096 16384; do
+  for p in 2 4 6 8; do
+    v=$(SPARTACUS_PIPES=$p SPARTACUS_SCRATCH_MB=$mb timeout -k 10 200 python bench.py --steps 4 --warmup 1 --no-extras 2>/dev/null | python -c "import json,sys; print('%.3e' % json.loads(sys.stdin.read().strip().splitlines()[-1])['value'])")
+    echo "scratch ${mb} MB pipes $p: $v"
+  done
 done
