@@ -342,8 +342,9 @@ int ss_host_entry_plan_creations(int64_t *count);
  * dscale0 (nmat, ndir) / dscale (nmat, ndiff): optional scaling vectors d with
  * diag(d)^-1 Gamma diag(d) symmetric (the solver passes sqrt(region fraction) and
  * sqrt(fraction * weight * mu)); with them orders 3..6 take the symmetric
- * eigen-route, NULL = the reference's general route.  sym_route (nmat, optional)
- * receives 1 where the symmetric route was taken.  mu0 is accepted for the
+ * eigen-route and orders 7..16 the cooperative Jacobi route (two more launches),
+ * NULL = the reference's general route.  sym_route (nmat, optional) receives 1
+ * where the symmetric route was taken, 2 for the cooperative route, else 0.  mu0 is accepted for the
  * reference's signature and unused, as in the reference (:377, :384). */
 int ss_calc_matrices_sw_eig(int32_t nmat, int32_t ndiff, int32_t ndir, double dz, double mu0,
                             const double *gamma0, const double *gamma1, const double *gamma2,

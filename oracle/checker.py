@@ -237,7 +237,7 @@ def calc_matrices_sw_eig(dz, mu0, gamma0, gamma1, gamma2, gamma3, which="ref"):
              s_up=z(nmat, nd, nr), s_dn=z(nmat, nd, nr), trans_dir=z(nmat, nr, nr),
              int_dir=z(nmat, nr, nr), int_diff=z(nmat, nd, nd),
              int_dir_diff=z(nmat, nd, nr))
-    lib = _load(REF_LIB if which == "ref" else ORACLE_LIB)
+    lib = _load(REF_LIB if which == "ref" else ORACLE_QUAD_LIB if which == "quad" else ORACLE_LIB)
     fn = getattr(lib, ("ref_" if which == "ref" else "oracle_") + "calc_matrices_sw_eig")
     fn(C.c_int32(nmat), C.c_int32(nd), C.c_int32(nr), C.c_double(dz), C.c_double(mu0),
        _p(g0), _p(g1), _p(g2), _p(g3), *[_p(o[k]) for k in
@@ -252,7 +252,7 @@ def calc_matrices_lw_eig(dz, gamma1, gamma2, emiss_rate, which="ref"):
     z = lambda *s: np.zeros(s, order="F")  # noqa: E731
     o = dict(reflectance=z(nmat, n, n), transmittance=z(nmat, n, n), source=z(nmat, n),
              int_flux=z(nmat, n, n), int_flux_source=z(nmat, n))
-    lib = _load(REF_LIB if which == "ref" else ORACLE_LIB)
+    lib = _load(REF_LIB if which == "ref" else ORACLE_QUAD_LIB if which == "quad" else ORACLE_LIB)
     fn = getattr(lib, ("ref_" if which == "ref" else "oracle_") + "calc_matrices_lw_eig")
     fn(C.c_int32(nmat), C.c_int32(n), C.c_double(dz), _p(g1), _p(g2), _p(b),
        *[_p(o[k]) for k in ("reflectance", "transmittance", "source", "int_flux",

@@ -85,6 +85,66 @@ __global__ void __launch_bounds__(256) k_scale_sum(const ss::ScaleSumLaunch S) {
 
 enum Family { FAM_SW_LAYER = 0, FAM_SW_COLUMN, FAM_LW_LAYER, FAM_LW_COLUMN, FAM_MISC, FAM_SW_DOWN, FAM_LW_DOWN, FAM_COUNT };
 
+// Optional pinning of the caller's arrays (SPARTACUS_PIN_HOST=1 or ss_host_pin): a host model
+// keeps its allocatable arrays for the whole run and calls radsurf every time step, so the
+// arrays can be page-locked ONCE (hipHostRegister); every later copy is then a direct DMA at
+// PCIe rate that does not block the host thread, and uploads, kernels and downloads of
+// successive chunks overlap in both directions.  Pageable arrays (the default) go through the
+// runtime's staging path, which blocks the calling thread per copy.
+// The registry never unpins by itself: ss_host_unpin_all() does (call it before freeing arrays).
+struct PinRegistry {
+  std::map<const void*, size_t> ranges;     // base -> bytes
+  std::map<const void*, char*> devbase;     // base -> the same memory as the device sees it
+  size_t bytes = 0;
+  // device address of a page-locked host address, or nullptr
+  double* device_view(const void* p, size_t n) const {
+    auto it = ranges.upper_bound(p);
+    if (it == ranges.begin()) return nullptr;
+    --it;
+    if ((const char*)p + n > (const char*)it->first + it->second) return nullptr;
+    auto d = devbase.find(it->first);
+    if (d == devbase.end() || !d->second) return nullptr;
+    return reinterpret_cast<double*>(d->second + ((const char*)p - (const char*)it->first));
+  }
+  bool covered(const void* p, size_t n) const {
+    auto it = ranges.upper_bound(p);
+    if (it == ranges.begin()) return false;
+    --it;
+    return (const char*)p + n <= (const char*)it->first + it->second;
+  }
+  void pin(const void* p, size_t n) {
+    if (!p || n == 0 || covered(p, n)) return;
+    // drop registrations this range overlaps (the caller re-allocated): hipHostRegister rejects overlaps
+    for (auto it = ranges.begin(); it != ranges.end();) {
+      const char *a = (const char*)it->first, *b = a + it->second;
+      if (a < (const char*)p + n && (const char*)p < b) {
+        hipHostUnregister(const_cast<void*>(it->first));
+        bytes -= it->second;
+        devbase.erase(it->first);
+        it = ranges.erase(it);
+      } else {
+        ++it;
+      }
+    }
+    if (hipHostRegister(const_cast<void*>(p), n, hipHostRegisterMapped) == hipSuccess) {
+      ranges[p] = n;
+      bytes += n;
+      void* d = nullptr;
+      if (hipHostGetDevicePointer(&d, const_cast<void*>(p), 0) == hipSuccess) devbase[p] = static_cast<char*>(d);
+      else (void)hipGetLastError();
+    } else {
+      (void)hipGetLastError();      // stays pageable: slower, still correct
+    }
+  }
+  void unpin_all() {
+    for (auto& kv : ranges) hipHostUnregister(const_cast<void*>(kv.first));
+    ranges.clear();
+    devbase.clear();
+    bytes = 0;
+  }
+};
+PinRegistry g_pins;
+
 // Launch check: a kernel launch reports configuration errors through hipGetLastError
 #define SS_LAUNCH_CHECK() HIP_CHECK_THROW(hipGetLastError())
 
@@ -232,6 +292,23 @@ struct HipBackend {
     HIP_CHECK_THROW(hipMalloc(&p, n ? n : 8));
     return p;
   }
+  // A copy whose host range is only partly page-locked is rejected by the runtime.  That happens
+  // when arrays that were page-locked through this library (SPARTACUS_PIN_HOST / ss_host_pin) have
+  // been freed and the allocator has handed the pages to other arrays - outside the contract of
+  // the pinning option, but no reason to fail: drop every registration and copy again, pageable.
+  static void copy_async(void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t s) {
+    hipError_t e = hipMemcpyAsync(dst, src, n, kind, s);
+    if (e == hipErrorInvalidValue && g_pins.bytes > 0) {
+      (void)hipGetLastError();
+      HIP_CHECK_THROW(hipDeviceSynchronize());      // nothing may still be reading a registration
+      g_pins.unpin_all();
+      e = hipMemcpyAsync(dst, src, n, kind, s);
+    }
+    if (e != hipSuccess) {
+      g_last_error = std::string("hipMemcpyAsync: ") + hipGetErrorString(e);
+      throw e;
+    }
+  }
   void free(void* p) { if (p) hipFree(p); }
   // initialisation of freshly allocated arrays: same stream as the uploads that may follow into them
   void memset(void* p, int v, size_t n) {
@@ -245,7 +322,7 @@ struct HipBackend {
   // (one wait per call instead of one per array).
   void h2d(void* d, const void* h, size_t n) {
     if (!n) return;
-    HIP_CHECK_THROW(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, up_stream()));
+    copy_async(d, h, n, hipMemcpyHostToDevice, up_stream());
     up_pending_ = true;
   }
   // Downloads: on the download stream if one was lent (it first waits for everything queued on
@@ -261,13 +338,18 @@ struct HipBackend {
         HIP_CHECK_THROW(hipStreamWaitEvent(down_, gate_ev_, 0));
         main_dirty_ = false;
       }
-      HIP_CHECK_THROW(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, down_));
+      copy_async(h, d, n, hipMemcpyDeviceToHost, down_);
       down_pending_ = true;
       return;
     }
-    HIP_CHECK_THROW(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, stream()));
+    copy_async(h, d, n, hipMemcpyDeviceToHost, stream());
   }
   void gate_copies() {}      // copies queued now already run after everything queued before them
+  // (One copy KERNEL per chunk that stores straight into mapped host memory, instead of ~35
+  // DMA copies with ~30 us between them, was measured slower - 1.18e7 -> 0.90e7 columns/s: its
+  // workgroups wait for compute units that the solver's one-wave-per-SIMD kernels hold.)
+  void d2h_batch_begin() {}
+  void d2h_batch_end() {}
   // wait for this plan's work: uploads, kernels, and ITS downloads (not the other plan's on a lent stream)
   void sync() {
     if (up_ && up_pending_) join_uploads();
@@ -455,6 +537,21 @@ struct HostEntry {
   // one upload and one download stream for both sub-plans: each direction of the bus needs a
   // stream of its own to run at the same time as the other (HipBackend::set_transfer_streams)
   hipStream_t up = nullptr, down = nullptr;
+  // call-level device arrays of the per-column outputs (bc_out, the (nspec, ncol) and (ncol)
+  // members of the flux objects): the sub-plans write their chunk's slice of them, and they come
+  // back in ONE copy per member at the end of the call instead of one per member and chunk -
+  // these copies are 200-400 KB per chunk, all start-up latency on the download engine
+  std::map<std::string, std::pair<double*, size_t>> arena;
+  double* arena_get(const std::string& name, size_t elems) {
+    auto& a = arena[name];
+    if (a.second < elems) {
+      if (a.first) hipFree(a.first);
+      a.first = nullptr;
+      HIP_CHECK_THROW(hipMalloc(reinterpret_cast<void**>(&a.first), std::max<size_t>(elems, 1) * sizeof(double)));
+      a.second = elems;
+    }
+    return a.first;
+  }
   ss_config cfg;
   int profiles = -1, device = -1;
   long creations = 0;       // sub-plans built so far (tests: block calls must not re-create)
@@ -465,6 +562,9 @@ struct HostEntry {
   }
   void drop() {
     for (auto& p : slot) { delete p; p = nullptr; }
+    for (auto& kv : arena)
+      if (kv.second.first) hipFree(kv.second.first);
+    arena.clear();
     if (up) hipStreamDestroy(up);
     if (down) hipStreamDestroy(down);
     up = down = nullptr;
@@ -474,49 +574,6 @@ struct HostEntry {
 };
 HostEntry g_host;           // deliberately never destroyed at process exit (HIP may be gone)
 
-// Optional pinning of the caller's arrays (SPARTACUS_PIN_HOST=1 or ss_host_pin): a host model
-// keeps its allocatable arrays for the whole run and calls radsurf every time step, so the
-// arrays can be page-locked ONCE (hipHostRegister); every later copy is then a direct DMA at
-// PCIe rate that does not block the host thread, and uploads, kernels and downloads of
-// successive chunks overlap in both directions.  Pageable arrays (the default) go through the
-// runtime's staging path, which blocks the calling thread per copy.
-// The registry never unpins by itself: ss_host_unpin_all() does (call it before freeing arrays).
-struct PinRegistry {
-  std::map<const void*, size_t> ranges;     // base -> bytes
-  size_t bytes = 0;
-  bool covered(const void* p, size_t n) const {
-    auto it = ranges.upper_bound(p);
-    if (it == ranges.begin()) return false;
-    --it;
-    return (const char*)p + n <= (const char*)it->first + it->second;
-  }
-  void pin(const void* p, size_t n) {
-    if (!p || n == 0 || covered(p, n)) return;
-    // drop registrations this range overlaps (the caller re-allocated): hipHostRegister rejects overlaps
-    for (auto it = ranges.begin(); it != ranges.end();) {
-      const char *a = (const char*)it->first, *b = a + it->second;
-      if (a < (const char*)p + n && (const char*)p < b) {
-        hipHostUnregister(const_cast<void*>(it->first));
-        bytes -= it->second;
-        it = ranges.erase(it);
-      } else {
-        ++it;
-      }
-    }
-    if (hipHostRegister(const_cast<void*>(p), n, hipHostRegisterDefault) == hipSuccess) {
-      ranges[p] = n;
-      bytes += n;
-    } else {
-      (void)hipGetLastError();      // stays pageable: slower, still correct
-    }
-  }
-  void unpin_all() {
-    for (auto& kv : ranges) hipHostUnregister(const_cast<void*>(kv.first));
-    ranges.clear();
-    bytes = 0;
-  }
-};
-PinRegistry g_pins;
 
 void pin_call_arrays(const ss_config* cfg, const ss_canopy* can, const ss_sw_spectral* sw, const ss_lw_spectral* lw,
                      ss_bc_out* bc, ss_flux* const* fl) {
@@ -564,6 +621,7 @@ struct ChunkView {
   ss_lw_spectral lw;
   ss_bc_out bc;
   ss_flux fl[4];
+  ss_flux fl_layers[4];     // fl with the per-column members removed (what is downloaded per chunk)
   bool have_fl[4];
   std::vector<int32_t> istartlay;
 };
@@ -634,7 +692,42 @@ void make_view(const ss_canopy* can, const ss_sw_spectral* sw, const ss_lw_spect
       const long off = shape == 0 ? (long)nspec * c0 : shape == 1 ? (long)nspec * l0 : shape == 2 ? c0 : l0;
       m[F] = adv(src[F], off);
     }
+    v.fl_layers[k] = v.fl[k];
+    double** ml = &v.fl_layers[k].ground_dn;
+    for (int F = 0; F < ss::F_NFIELDS; ++F)
+      if (ss::flux_field_shape(F) == 0 || ss::flux_field_shape(F) == 2) ml[F] = nullptr;
   }
+}
+
+// the per-column output members of a call: name of the plan's device array, the caller's array,
+// doubles per column
+struct ColumnOutput {
+  std::string name;
+  double* host;
+  int width;
+};
+std::vector<ColumnOutput> column_outputs(const ss_config* cfg, ss_bc_out* bc, ss_flux* const* fl) {
+  static const char* obj[4] = {"sw_norm_dir", "sw_norm_diff", "lw_internal", "lw_norm"};
+  std::vector<ColumnOutput> out;
+  if (cfg->do_sw) {
+    if (bc->sw_albedo) out.push_back({"bc_out.sw_albedo", bc->sw_albedo, cfg->nsw});
+    if (bc->sw_albedo_dir) out.push_back({"bc_out.sw_albedo_dir", bc->sw_albedo_dir, cfg->nsw});
+  }
+  if (cfg->do_lw) {
+    if (bc->lw_emissivity) out.push_back({"bc_out.lw_emissivity", bc->lw_emissivity, cfg->nlw});
+    if (bc->lw_emission) out.push_back({"bc_out.lw_emission", bc->lw_emission, cfg->nlw});
+  }
+  for (int k = 0; k < 4; ++k) {
+    if (!fl[k]) continue;
+    double* const* m = &fl[k]->ground_dn;
+    for (int F = 0; F < ss::F_NFIELDS; ++F) {
+      const int shape = ss::flux_field_shape(F);
+      if ((shape == 0 || shape == 2) && m[F])
+        out.push_back({std::string(obj[k]) + "." + HipPlan::flux_field_name(F), m[F],
+                       shape == 0 ? (k < 2 ? cfg->nsw : cfg->nlw) : 1});
+    }
+  }
+  return out;
 }
 
 // Columns of the next chunk.  The downloads are the longest stage of the pipeline (C3: 2.9 KB
@@ -898,6 +991,11 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
     const bool pinned = canopy->dz && g_pins.covered(canopy->dz, sizeof(double) * (size_t)std::max(1, canopy->ntotlay));
     const bool always_seed = std::getenv("SPARTACUS_ALWAYS_SEED") != nullptr;
     const int c_begin = istartcol - 1, c_end = iendcol;
+    // per-column outputs: call-level device arrays, one download per member at the end
+    const std::vector<ColumnOutput> col_out = column_outputs(config, bc_out, fl);
+    std::vector<double*> col_dev(col_out.size());
+    for (size_t i = 0; i < col_out.size(); ++i)
+      col_dev[i] = g_host.arena_get(col_out[i].name, (size_t)col_out[i].width * (size_t)(c_end - c_begin));
     constexpr int NS = HostEntry::kSlots;
     ChunkView views[NS];
     bool inflight[NS] = {};     // results of the slot's chunk still on their way to the host
@@ -926,8 +1024,12 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
       const double tw = now();
       ChunkView& v = views[s];
       make_view(canopy, sw, lw, bc_out, fl, config->nsw, config->nlw, c0, c1, v);
-      if (!p) {
-        p = new HipPlan;
+      const bool fresh = !p;
+      if (fresh) p = new HipPlan;
+      for (size_t i = 0; i < col_out.size(); ++i)
+        p->bind_external(col_out[i].name, col_dev[i] + (size_t)col_out[i].width * (size_t)(c0 - c_begin),
+                         (size_t)col_out[i].width * (size_t)(c1 - c0));
+      if (fresh) {
         // one stream per sub-plan: the two sub-plans then sit on two hardware queues of their own, and
         // what this entry has to hide is PCIe time, not the (shorter) kernel time
         p->pipes_cap = 1;
@@ -953,7 +1055,9 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
       if (r) return fail(p, r);
       const double td = now();
       // the results come back as soon as the kernels are done; the host does not wait here
-      r = p->download_begin(&v.bc, fl_of(v, 0), fl_of(v, 1), fl_of(v, 2), fl_of(v, 3));
+      // (the per-layer members of this chunk; the per-column ones wait in the call-level arrays)
+      auto fll_of = [](ChunkView& vv, int kk) { return vv.have_fl[kk] ? &vv.fl_layers[kk] : nullptr; };
+      r = p->download_begin(nullptr, fll_of(v, 0), fll_of(v, 1), fll_of(v, 2), fll_of(v, 3));
       if (r) return fail(p, r);
       inflight[s] = true;
       if (timing)
@@ -966,6 +1070,17 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
       r = g_host.slot[s]->download_end();
       if (r) return fail(g_host.slot[s], r);
       if (timing) std::fprintf(stderr, "host entry: slot %d home after %.2f ms\n", s, now() - te);
+    }
+    // every kernel of the call has completed: the per-column outputs, one copy per member
+    {
+      const double te = now();
+      hipStream_t ds = g_host.down ? g_host.down : nullptr;
+      const size_t ncols = (size_t)(c_end - c_begin);
+      for (size_t i = 0; i < col_out.size(); ++i)
+        HipBackend::copy_async(col_out[i].host + (size_t)col_out[i].width * (size_t)c_begin, col_dev[i],
+                               (size_t)col_out[i].width * ncols * sizeof(double), hipMemcpyDeviceToHost, ds);
+      HIP_CHECK_THROW(hipStreamSynchronize(ds));
+      if (timing) std::fprintf(stderr, "host entry: %zu per-column members home after %.2f ms\n", col_out.size(), now() - te);
     }
     if (timing) std::fprintf(stderr, "host entry total %.2f ms\n", now() - t_start);
     if (nocache) g_host.drop();

@@ -175,7 +175,9 @@ class Plan {
   ~Plan() { release(); }
 
   void release() {
-    for (auto& kv : dev) be.free(kv.second);
+    for (auto& kv : dev)
+      if (!dev_external.count(kv.first) || !dev_external[kv.first]) be.free(kv.second);
+    dev_external.clear();
     dev.clear();
     dev_elems.clear();
     dev_cap.clear();
@@ -245,7 +247,21 @@ class Plan {
   // Device arrays only grow: a plan that is re-targeted to another column set
   // (reset(), the host entry's chunk loop and block calls) keeps its allocations;
   // dev_elems is the logical size, dev_cap the allocated one (both in elements).
+  // An array may live outside the plan (bind_external: the host entry keeps the per-column
+  // outputs of a whole call in call-level arrays, so that they come back in one copy per member
+  // instead of one per member and chunk): the plan then neither sizes nor frees it.
+  std::map<std::string, bool> dev_external;
+  void bind_external(const std::string& name, void* p, size_t elems) {
+    auto it = dev.find(name);
+    if (it != dev.end() && !dev_external[name]) be.free(it->second);
+    dev[name] = p;
+    dev_elems[name] = elems;
+    dev_cap[name] = elems;
+    dev_external[name] = true;
+  }
   void ensure(const std::string& name, size_t elems, size_t elsize = sizeof(double)) {
+    auto ex = dev_external.find(name);
+    if (ex != dev_external.end() && ex->second) return;
     auto it = dev.find(name);
     if (it != dev.end() && dev_cap[name] >= elems) { dev_elems[name] = elems; return; }
     if (it != dev.end()) be.free(it->second);
@@ -896,7 +912,9 @@ class Plan {
   // are complete.
   int download_begin(ss_bc_out* bc, ss_flux* sw_dir, ss_flux* sw_diff, ss_flux* lw_int, ss_flux* lw_nrm) {
     be.gate_copies();
+    be.d2h_batch_begin();
     const int rc = download_queue(bc, sw_dir, sw_diff, lw_int, lw_nrm);
+    be.d2h_batch_end();
     be.downloads_queued();
     return rc;
   }

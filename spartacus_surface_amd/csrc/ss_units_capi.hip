@@ -18,6 +18,7 @@
 #include "ss_common.hpp"
 #include "ss_eigen.hpp"
 #include "ss_eigen_sym.hpp"
+#include "ss_eigen_coop.hpp"
 #include "ss_layer_matrices.hpp"
 #include "ss_linalg.hpp"
 
@@ -31,6 +32,7 @@ struct UnitArgs {
   double *o0, *o1, *o2, *o3, *o4, *o5, *o6, *o7;
   int32_t* route;
   int force_dynamic;
+  double* eig;          // eigen records of the cooperative eigen-solver (orders 7..16 with dscale), else nullptr
 };
 
 // element (i, j) of problem m in a stack x(nmat, R, C)
@@ -83,7 +85,11 @@ __global__ void __launch_bounds__(64) k_unit_sw(const UnitArgs A) {
     }
     A.route[m] = r;
   }
-  ss::calc_matrices_sw<N, D, N, D, 0, 0>(g0, g1, g2, g3, A.dsc0 ? dsc0 : nullptr, A.dsc ? dsc : nullptr, A.dz, w);
+  const ss::CoopEig ce{A.eig ? A.eig + ss::rec_base(0, 1, ss::EigRec<N>::NELEM, m) : nullptr, ss::kRecStride};
+  if (A.route && ss::coop_order(N) && A.eig)
+    A.route[m] = ss::rec_elem_load(ce.rec, ce.stride, ss::EigRec<N>::STATUS) > 0.5 ? 2 : 0;   // 2 = cooperative Jacobi
+  ss::calc_matrices_sw<N, D, N, D, 0, 0>(g0, g1, g2, g3, A.dsc0 ? dsc0 : nullptr, A.dsc ? dsc : nullptr, A.dz, w,
+                                         A.eig ? &ce : nullptr);
   __threadfence();
   rec_to_stack<N, N>(rec, Rec::R, A.o0, A.nmat, m);
   rec_to_stack<N, N>(rec, Rec::T, A.o1, A.nmat, m);
@@ -126,13 +132,36 @@ __global__ void __launch_bounds__(64) k_unit_lw(const UnitArgs A) {
   if (A.dsc) load_stack<N, 1>(A.dsc, A.nmat, m, dsc);
   double* rec = A.rec + ss::rec_base(0, 1, Rec::NELEM, m);
   ss::RecWriter w{rec, ss::kRecStride, nullptr};
-  ss::calc_matrices_lw<N, N, 0>(g1, g2, b, A.dsc ? dsc : nullptr, A.dz, w);
+  const ss::CoopEig ce{A.eig ? A.eig + ss::rec_base(0, 1, ss::EigRec<N>::NELEM, m) : nullptr, ss::kRecStride};
+  ss::calc_matrices_lw<N, N, 0>(g1, g2, b, A.dsc ? dsc : nullptr, A.dz, w, A.eig ? &ce : nullptr);
   __threadfence();
   rec_to_stack<N, N>(rec, Rec::R, A.o0, A.nmat, m);
   rec_to_stack<N, N>(rec, Rec::T, A.o1, A.nmat, m);
   rec_to_stack<N, 1>(rec, Rec::SRC, A.o2, A.nmat, m);
   rec_to_stack<N, N>(rec, Rec::IFLUX, A.o3, A.nmat, m);
   rec_to_stack<N, 1>(rec, Rec::ISRC, A.o4, A.nmat, m);
+}
+
+// the two extra launches of the cooperative eigen route (ss_eigen_coop.hpp): W of every problem,
+// then the Jacobi iteration on 4 lanes per problem
+template <int N>
+__global__ void __launch_bounds__(64) k_unit_coop_pre(const UnitArgs A) {
+  const int m = blockIdx.x * 64 + threadIdx.x;
+  if (m >= A.nmat) return;
+  double g1[N * N], g2[N * N], dsc[N];
+  load_stack<N, N>(A.g1, A.nmat, m, g1);
+  load_stack<N, N>(A.g2, A.nmat, m, g2);
+  load_stack<N, 1>(A.dsc, A.nmat, m, dsc);
+  for (int k = 0; k < N * N; ++k) g1[k] = g1[k] - g2[k];
+  ss::coop_eig_pre<N>(g1, g2, dsc, A.eig + ss::rec_base(0, 1, ss::EigRec<N>::NELEM, m), ss::kRecStride);
+}
+template <int N>
+__global__ void __launch_bounds__(64) k_unit_coop_eig(const UnitArgs A) {
+  const int m = blockIdx.x * 16 + ((int)threadIdx.x >> 2);
+  if (m >= A.nmat) return;
+  if constexpr (ss::coop_order(N))
+    ss::coop_eig_unit<N, ss::kCoopLanes>(A.eig + ss::rec_base(0, 1, ss::EigRec<N>::NELEM, m), ss::kRecStride,
+                                         (int)threadIdx.x & 3);
 }
 
 template <int N>
@@ -184,14 +213,22 @@ int finish(Stage& s, const char* what) {
   return SS_OK;
 }
 
+#define UNIT_COOP(NN)                                                                               \
+  if (ss::coop_order(NN) && A.dsc) {                                                                \
+    A.eig = static_cast<double*>(s.raw(tiles * 64 * (size_t)ss::EigRec<NN>::NELEM * sizeof(double)));   \
+    if (s.err == hipSuccess) hipLaunchKernelGGL((k_unit_coop_pre<NN>), dim3(tiles), dim3(64), 0, 0, A); \
+    if (s.err == hipSuccess) hipLaunchKernelGGL((k_unit_coop_eig<NN>), dim3((nmat + 15) / 16), dim3(64), 0, 0, A); \
+  }
 #define UNIT_SW_CASE(NN, DD)                                                                        \
   if (ndiff == NN && ndir == DD) {                                                                  \
+    UNIT_COOP(NN)                                                                                   \
     A.rec = static_cast<double*>(s.raw(tiles * 64 * (size_t)ss::SwRec<NN, DD>::NELEM * sizeof(double))); \
     if (s.err == hipSuccess) hipLaunchKernelGGL((k_unit_sw<NN, DD>), dim3(tiles), dim3(64), 0, 0, A);   \
     launched = true;                                                                                \
   }
 #define UNIT_LW_CASE(NN)                                                                            \
   if (norder == NN) {                                                                               \
+    UNIT_COOP(NN)                                                                                   \
     A.rec = static_cast<double*>(s.raw(tiles * 64 * (size_t)ss::LwRec<NN>::NELEM * sizeof(double)));   \
     if (s.err == hipSuccess) hipLaunchKernelGGL((k_unit_lw<NN>), dim3(tiles), dim3(64), 0, 0, A);       \
     launched = true;                                                                                \

@@ -32,6 +32,8 @@ struct EmulBackend {
   static void arena_reset() {}
   static void gate_copies() {}
   static void downloads_queued() {}
+  static void d2h_batch_begin() {}
+  static void d2h_batch_end() {}
   static void d2h(void* h, const void* d, size_t n) { std::memcpy(h, d, n); }
   static void sync() {}
 
