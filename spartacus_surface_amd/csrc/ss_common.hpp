@@ -49,6 +49,17 @@
 #define SS_LOAD_FENCE() do {} while (0)
 #endif
 
+// Ordering point for ONE value: the (empty) volatile asm "modifies" x, so everything that
+// defines x comes before it, everything that uses x after it, and volatile asms keep their program
+// order among themselves.  A chain of them pins the order of otherwise independent steps of fully
+// unrolled code - the scheduler then cannot run the loads / broadcasts of ten steps ahead of the
+// arithmetic of the first (it does, with a 512-register budget, and the register file overflows).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SS_PIN(x) asm volatile("" : "+v"(x))
+#else
+#define SS_PIN(x) do {} while (0)
+#endif
+
 namespace ss {
 
 // Per-lane staging space in LDS for the downward kernels: kLaneLdsSlots doubles

@@ -36,7 +36,14 @@
 
 namespace ss {
 
-constexpr int kCoopLanes = 4;
+// lanes per problem of the Jacobi kernel: 4 (three matrices of N^2 / 4 doubles per lane fit its
+// registers; 1.8 ms per 500 000 12 x 12 problems against 2.8 ms with 8)
+#ifndef SS_COOP_LANES
+#define SS_COOP_LANES 4
+#endif
+constexpr int kCoopLanes = SS_COOP_LANES;
+// which spectral regions run the layer matrices of the cooperative units on the 16 lanes of a DPP row (ss_layer16.hpp)
+constexpr bool r16_layer(int n, bool lw);
 constexpr int kCoopMaxOrder = 16;
 constexpr bool coop_order(int n) {
 #if defined(SS_NO_COOP_EIGEN)
@@ -46,16 +53,45 @@ constexpr bool coop_order(int n) {
 #endif
 }
 
-// Eigen record of one (column, band, layer) unit in the tiling of the scratch records:
-//   [0] status (1 = W valid / eigen-decomposition valid, 0 = not a cooperative unit), [1] unused,
-//   [EV .. EV + N) squared singular values, [MAT .. MAT + N*N) W, later Y, ROW-major
+constexpr bool r16_layer(int n, bool lw) {
+#if defined(SS_NO_R16_LAYER)
+  return false && n > 0 && lw;
+#else
+  return coop_order(n) && lw;
+#endif
+}
+
+// Eigen record of one (column, band, layer) unit in the tiling of the scratch records (all
+// matrices ROW-major, so that a lane of the cooperative kernels loads its rows):
+//   [0] status (1 = a cooperative unit, 0 = not), [1] layer thickness dz,
+//   EV    squared singular values (out)
+//   W     W = F^T L (in)
+//   X     D L in,  eigenvectors X = D L Y out   (the rotations are accumulated into D L ...
+//   AX    -D L^-T in, (G1 - G2)^-1 X = -D L^-T Y out   ... and into -D L^-T instead of into I)
+//   G1, G2, VEC: the Gamma matrices and vectors of the unit for the layer kernel in the row-of-16
+//   layout (ss_layer16.hpp); VEC = [dscale (N)] [b (N), longwave] or [g0 (D*D) g3 (N*D, row-major) dscale0 (D), shortwave]
 template <int N>
 struct EigRec {
   static constexpr int STATUS = 0;
   static constexpr int EV = 2;
-  static constexpr int MAT = EV + rec_even(N);
-  static constexpr int NELEM = MAT + rec_even(N * N);
+  static constexpr int W = EV + rec_even(N);
+  static constexpr int X = W + rec_even(N * N);
+  static constexpr int AX = X + rec_even(N * N);
+  static constexpr int G1 = AX + rec_even(N * N);
+  static constexpr int G2 = G1 + rec_even(N * N);
+  static constexpr int VEC = G2 + rec_even(N * N);
+  static constexpr int NVEC = 2 * N + 3 * 3 + 3 * N + 4;    // room for either spectral region (D <= 3)
+  static constexpr int NELEM = VEC + rec_even(NVEC);
 };
+
+// element e of a record, read as a scalar (pairs: element e sits at pair e/2, half e%2)
+SS_HD double rec_elem_load(const double* rec, long stride, int e) {
+  return rec[(long)(e & ~1) * stride + (e & 1)];
+}
+// store element e of a record (scalar; elements 2p, 2p+1 share a 16-byte pair)
+SS_HD void rec_elem_store(double* rec, long stride, int e, double v) {
+  rec[(long)(e & ~1) * stride + (e & 1)] = v;
+}
 
 // ---- pass 1 of the layer kernel: W = F^T L from the Gamma matrices (one lane per problem) ----
 // A = G1 - G2, g2 = G2, dscale = D.  Returns false (status 0) when the structure is not there
@@ -105,32 +141,33 @@ SS_HD bool coop_eig_pre(const double* A, const double* G2, const double* dscale,
   };
   chol(C);
   chol(M);
-  rec_pair_store(rec + (long)EigRec<N>::STATUS * stride, ok ? 1.0 : 0.0, 0.0);
+  rec_elem_store(rec, stride, EigRec<N>::STATUS, ok ? 1.0 : 0.0);
   if (!ok) return false;
-  // W = F^T L: W(i, j) = sum_{k >= max(i, j)} F(k, i) L(k, j); stored row-major, pairs along a row
-  for (int i = 0; i < N; ++i) {
-    for (int j = 0; j < N; j += 2) {
-      double w0 = 0.0, w1 = 0.0;
+  // W = F^T L: W(i, j) = sum_{k >= max(i, j)} F(k, i) L(k, j)
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+      double w0 = 0.0;
       for (int k = (i > j ? i : j); k < N; ++k) w0 += SS_E(M, k, i, N) * SS_E(C, k, j, N);
-      if (j + 1 < N)
-        for (int k = (i > j + 1 ? i : j + 1); k < N; ++k) w1 += SS_E(M, k, i, N) * SS_E(C, k, j + 1, N);
-      if (((i * N + j) & 1) == 0) {
-        rec_pair_store(rec + (long)(EigRec<N>::MAT + i * N + j) * stride, w0, w1);
-      } else {
-        // (odd N: a row does not start at an even element - element-wise through the pair it shares)
-        double* p = rec + (long)(EigRec<N>::MAT + i * N + j - 1) * stride;
-        p[1] = w0;
-        if (j + 1 < N) (rec + (long)(EigRec<N>::MAT + i * N + j + 1) * stride)[0] = w1;
-      }
+      rec_elem_store(rec, stride, EigRec<N>::W + i * N + j, w0);
+    }
+  // the two matrices the rotations are accumulated into: D L, and -D L^-T (M is free: L^-1 into it)
+  for (int j = 0; j < N; ++j) {
+    for (int i = 0; i < j; ++i) SS_E(M, i, j, N) = 0.0;
+    SS_E(M, j, j, N) = 1.0 / SS_E(C, j, j, N);
+    for (int i = j + 1; i < N; ++i) {
+      double t = 0.0;
+      for (int k = j; k < i; ++k) t -= SS_E(C, i, k, N) * SS_E(M, k, j, N);
+      SS_E(M, i, j, N) = t / SS_E(C, i, i, N);
     }
   }
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+      rec_elem_store(rec, stride, EigRec<N>::X + i * N + j, (j <= i) ? dscale[i] * SS_E(C, i, j, N) : 0.0);
+      rec_elem_store(rec, stride, EigRec<N>::AX + i * N + j, (j >= i) ? -dscale[i] * SS_E(M, j, i, N) : 0.0);
+    }
   return true;
 }
 
-// element e of a record, read as a scalar (pairs: element e sits at pair e/2, half e%2)
-SS_HD double rec_elem_load(const double* rec, long stride, int e) {
-  return rec[(long)(e & ~1) * stride + (e & 1)];
-}
 
 // ---- pass 2 of the layer kernel: eigenvalues / vectors from the record ----
 // Same outputs as eigen_decomposition_gamma_sym: eigenvalue, eigenvector X = D L Y, ainv_x =
@@ -138,40 +175,14 @@ SS_HD double rec_elem_load(const double* rec, long stride, int e) {
 template <int N>
 SS_HD int coop_eig_post(const double* A, const double* dscale, const double* rec, long stride,
                         double* eigenvalue, double* eigenvector, double* ainv_x) {
+  (void)A; (void)dscale;
   if (!(rec_elem_load(rec, stride, EigRec<N>::STATUS) > 0.5)) return -1;
-  // L again (a third of an n^3 - cheaper than carrying it through memory)
-  double C[N * N], rd[N], rl[N];
-  for (int i = 0; i < N; ++i) rd[i] = 1.0 / dscale[i];
-  for (int j = 0; j < N; ++j)
-    for (int i = j; i < N; ++i) SS_E(C, i, j, N) = -SS_E(A, i, j, N) * (dscale[j] * rd[i]);
-  for (int j = 0; j < N; ++j) {
-    double s = SS_E(C, j, j, N);
-    for (int k = 0; k < j; ++k) s -= SS_E(C, j, k, N) * SS_E(C, j, k, N);
-    const double ljj = sqrt(s);
-    SS_E(C, j, j, N) = ljj;
-    rl[j] = 1.0 / ljj;
-    for (int i = j + 1; i < N; ++i) {
-      double t = SS_E(C, i, j, N);
-      for (int k = 0; k < j; ++k) t -= SS_E(C, i, k, N) * SS_E(C, j, k, N);
-      SS_E(C, i, j, N) = t * rl[j];
-    }
-  }
   for (int j = 0; j < N; ++j) eigenvalue[j] = rec_elem_load(rec, stride, EigRec<N>::EV + j);
-  for (int j = 0; j < N; ++j) {
-    double y[N], v[N];
-    for (int i = 0; i < N; ++i) y[i] = rec_elem_load(rec, stride, EigRec<N>::MAT + i * N + j);   // Y(i, j), row-major
-    for (int i = 0; i < N; ++i) {
-      double s = 0.0;
-      for (int k = 0; k <= i; ++k) s += SS_E(C, i, k, N) * y[k];
-      SS_E(eigenvector, i, j, N) = dscale[i] * s;
+  for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+      SS_E(eigenvector, i, j, N) = rec_elem_load(rec, stride, EigRec<N>::X + i * N + j);
+      SS_E(ainv_x, i, j, N) = rec_elem_load(rec, stride, EigRec<N>::AX + i * N + j);
     }
-    for (int i = N - 1; i >= 0; --i) {
-      double s = y[i];
-      for (int k = i + 1; k < N; ++k) s -= SS_E(C, k, i, N) * v[k];
-      v[i] = s * rl[i];
-      SS_E(ainv_x, i, j, N) = -dscale[i] * v[i];
-    }
-  }
   return 0;
 }
 
@@ -194,21 +205,22 @@ SS_HD void coop_eig_unit(double* rec, long stride, int q) {
   constexpr int NR = (N + G - 1) / G;
   using Rec = EigRec<N>;
   if (!(rec_elem_load(rec, stride, Rec::STATUS) > 0.5)) return;   // same for the whole group
-  double w[NR][N], y[NR][N];
+  double w[NR][N], x[NR][N], ax[NR][N];
   SS_UNROLL_FULL
   for (int r = 0; r < NR; ++r) {
     const int i = q + r * G;
     SS_UNROLL_FULL
     for (int j = 0; j < N; ++j) {
-      w[r][j] = (i < N) ? rec_elem_load(rec, stride, Rec::MAT + i * N + j) : 0.0;
-      y[r][j] = (i == j) ? 1.0 : 0.0;
+      w[r][j] = (i < N) ? rec_elem_load(rec, stride, Rec::W + i * N + j) : 0.0;
+      x[r][j] = (i < N) ? rec_elem_load(rec, stride, Rec::X + i * N + j) : 0.0;
+      ax[r][j] = (i < N) ? rec_elem_load(rec, stride, Rec::AX + i * N + j) : 0.0;
     }
   }
-  auto gsum = [](double x) {
+  auto gsum = [](double v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return group_sum<G>(x);
+    return group_sum<G>(v);
 #else
-    return x;
+    return v;
 #endif
   };
   // cyclic sweeps; a sweep without a rotation ends the iteration (the decision is taken on
@@ -238,25 +250,27 @@ SS_HD void coop_eig_unit(double* rec, long stride, int q) {
           const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
           SS_UNROLL_FULL
           for (int r = 0; r < NR; ++r) {
-            const double wp = w[r][p], wc = w[r][c], yp = y[r][p], yc = y[r][c];
+            const double wp = w[r][p], wc = w[r][c], xp = x[r][p], xc = x[r][c], ap = ax[r][p], ac = ax[r][c];
             w[r][p] = cs * wp - sn * wc;
             w[r][c] = sn * wp + cs * wc;
-            y[r][p] = cs * yp - sn * yc;
-            y[r][c] = sn * yp + cs * yc;
+            x[r][p] = cs * xp - sn * xc;
+            x[r][c] = sn * xp + cs * xc;
+            ax[r][p] = cs * ap - sn * ac;
+            ax[r][c] = sn * ap + cs * ac;
           }
         }
       }
     }
     if (!rotated) break;
   }
-  // squared singular values, and Y in place of W
+  // squared singular values; X and (G1 - G2)^-1 X in place of D L and -D L^-T
   SS_UNROLL_FULL
   for (int j = 0; j < N; ++j) {
     double s = 0.0;
     SS_UNROLL_FULL
     for (int r = 0; r < NR; ++r) s += w[r][j] * w[r][j];
     s = gsum(s);
-    if (q == (j % G)) (rec + (long)((Rec::EV + j) & ~1) * stride)[(Rec::EV + j) & 1] = s;
+    if (q == (j % G)) rec_elem_store(rec, stride, Rec::EV + j, s);
   }
   SS_UNROLL_FULL
   for (int r = 0; r < NR; ++r) {
@@ -264,8 +278,8 @@ SS_HD void coop_eig_unit(double* rec, long stride, int q) {
     if (i < N) {
       SS_UNROLL_FULL
       for (int j = 0; j < N; ++j) {
-        const int e = Rec::MAT + i * N + j;
-        (rec + (long)(e & ~1) * stride)[e & 1] = y[r][j];
+        rec_elem_store(rec, stride, Rec::X + i * N + j, x[r][j]);
+        rec_elem_store(rec, stride, Rec::AX + i * N + j, ax[r][j]);
       }
     }
   }

@@ -6,6 +6,7 @@
 #include "ss_column_sw.hpp"
 #include "ss_solver_lw.hpp"
 #include "ss_solver_sw.hpp"
+#include "ss_layer16.hpp"
 
 namespace ss {
 namespace {
@@ -51,15 +52,15 @@ __global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_LAYER)) k
 // cooperative eigen-solver between the two passes of the layer kernel (ss_eigen_coop.hpp):
 // block -> (tile of 64 units, layer, quarter of the tile); 4 lanes per unit, 16 units per wave
 template <int N>
-__global__ void __launch_bounds__(kBlock, 2) k_eig_coop(const Launch L) {
-  const int quarter = blockIdx.x & 3, tl = blockIdx.x >> 2;
+__global__ void __launch_bounds__(kBlock, 1) k_eig_coop(const Launch L) {
+  constexpr int G = kCoopLanes;
+  const int part = blockIdx.x % G, tl = blockIdx.x / G;
   const int tile = tl / L.maxlay, jlay = tl % L.maxlay;
-  const int cu = tile * kBlock + quarter * 16 + ((int)threadIdx.x >> 2);
+  const int cu = tile * kBlock + part * (kBlock / G) + (int)threadIdx.x / G;
   if (cu >= L.ncu) return;
   if (jlay >= L.in.nlay[L.cols[cu / L.nspec]]) return;
   if constexpr (coop_order(N))
-    coop_eig_unit<N, kCoopLanes>(L.eig + rec_base(jlay, L.maxlay, EigRec<N>::NELEM, cu), kRecStride,
-                                 (int)threadIdx.x & 3);
+    coop_eig_unit<N, G>(L.eig + rec_base(jlay, L.maxlay, EigRec<N>::NELEM, cu), kRecStride, (int)threadIdx.x % G);
 }
 
 // layer matrices + upward sweep of a column unit on one lane (orders that live in registers)
@@ -70,6 +71,24 @@ __global__ void __launch_bounds__(kBlock, 1) k_layer_up(const Launch L) {
   if constexpr (fused_order(R * NS, LW)) {
     if constexpr (LW) layer_up_lw<U, R, NS>(L, cu);
     else layer_up_sw<U, R, NS>(L, cu);
+  }
+}
+
+// layer matrices of the cooperative units on the 16 lanes of a DPP row (ss_layer16.hpp):
+// block -> (tile of 64 units, layer, sixteenth of the tile); 4 units per wave
+template <int N, bool LW>
+__global__ void __launch_bounds__(kBlock, 2) k_layer16(const Launch L) {
+  constexpr int UPB = kBlock / r16::kRow;          // units per block
+  const int part = blockIdx.x % r16::kRow, tl = blockIdx.x / r16::kRow;
+  const int tile = tl / L.maxlay, jlay = tl % L.maxlay;
+  const int cu = tile * kBlock + part * UPB + (int)threadIdx.x / r16::kRow;
+  if (cu >= L.ncu) return;
+  if (jlay >= L.in.nlay[L.cols[cu / L.nspec]]) return;
+  if constexpr (r16_layer(N, LW)) {
+    const double* erec = L.eig + rec_base(jlay, L.maxlay, EigRec<N>::NELEM, cu);
+    if (!(rec_elem_load(erec, kRecStride, EigRec<N>::STATUS) > 0.5)) return;     // same for the whole row
+    if constexpr (LW)
+      r16::layer_lw<N>(erec, kRecStride, L.lay + rec_base(jlay, L.maxlay, LwRec<N>::NELEM, cu));
   }
 }
 
@@ -131,8 +150,13 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev) {
     hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0, 1>), glayer, dim3(kBlock), 0,
                        stream, L);
     SS_TRY(hipGetLastError());
-    hipLaunchKernelGGL((k_eig_coop<SS_INST_NREG * NS>), dim3(gx * (unsigned)L.maxlay * 4), dim3(kBlock), 0, stream, L);
+    hipLaunchKernelGGL((k_eig_coop<SS_INST_NREG * NS>), dim3(gx * (unsigned)L.maxlay * kCoopLanes), dim3(kBlock), 0, stream, L);
     SS_TRY(hipGetLastError());
+    if constexpr (r16_layer(SS_INST_NREG * NS, SS_INST_LW != 0)) {
+      hipLaunchKernelGGL((k_layer16<SS_INST_NREG * NS, SS_INST_LW != 0>), dim3(gx * (unsigned)L.maxlay * r16::kRow),
+                         dim3(kBlock), 0, stream, L);
+      SS_TRY(hipGetLastError());
+    }
     hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0, 2>), glayer, dim3(kBlock), 0,
                        stream, L);
     SS_TRY(hipGetLastError());

@@ -97,7 +97,7 @@ inline int col_nelem(bool lw, const ClassKey& k) {
 inline int eig_nelem(const ClassKey& k) {
   const int n = k.nreg * k.ns;
   auto ev = [](int x) { return (x + 1) & ~1; };
-  return coop_order(n) ? 2 + ev(n) + ev(n * n) : 0;
+  return coop_order(n) ? 2 + ev(n) + 5 * ev(n * n) + ev(2 * n + 9 + 3 * n + 4) : 0;
 }
 
 // Runtime (urban, nreg, ns) -> template instance

@@ -110,6 +110,11 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
   const int col = L.cols[cu / L.nspec];
   const int jb = cu % L.nspec;
   if (jlay >= in.nlay[col]) return;
+  if constexpr (STAGE == 2 && r16_layer(NREG * NS, true)) {
+    // units of the cooperative route had their layer matrices computed by the row-of-16 kernel
+    if (rec_elem_load(L.eig + rec_base(jlay, L.maxlay, EigRec<NREG * NS>::NELEM, cu), kRecStride,
+                      EigRec<NREG * NS>::STATUS) > 0.5) return;
+  }
 
   // per-layer inputs from the input pack (ss_pack.hpp)
   LwLayerIn<URBAN, NREG> raw;
@@ -207,9 +212,20 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
     if (full) {
       double GD[N * N];
       for (int k = 0; k < N * N; ++k) GD[k] = g1[k] - g2[k];
-      coop_eig_pre<N>(GD, g2, dsc, erec, kRecStride);
+      if (coop_eig_pre<N>(GD, g2, dsc, erec, kRecStride) && r16_layer(N, true)) {
+        // what the layer kernel of the row-of-16 layout (ss_layer16.hpp) needs of this unit, row-major
+        rec_elem_store(erec, kRecStride, 1, p.g.dz);
+        for (int i = 0; i < N; ++i) {
+          for (int j = 0; j < N; ++j) {
+            rec_elem_store(erec, kRecStride, EigRec<N>::G1 + i * N + j, SS_E(g1, i, j, N));
+            rec_elem_store(erec, kRecStride, EigRec<N>::G2 + i * N + j, SS_E(g2, i, j, N));
+          }
+          rec_elem_store(erec, kRecStride, EigRec<N>::VEC + i, dsc[i]);
+          rec_elem_store(erec, kRecStride, EigRec<N>::VEC + N + i, b[i]);
+        }
+      }
     } else {
-      rec_pair_store(erec + (long)EigRec<N>::STATUS * kRecStride, 0.0, 0.0);
+      rec_elem_store(erec, kRecStride, EigRec<N>::STATUS, 0.0);
     }
     return;
   }

@@ -194,7 +194,7 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
       for (int k = 0; k < N * N; ++k) GD[k] = g1[k] - g2[k];
       coop_eig_pre<N>(GD, g2, dsc, erec, kRecStride);
     } else {
-      rec_pair_store(erec + (long)EigRec<N>::STATUS * kRecStride, 0.0, 0.0);
+      rec_elem_store(erec, kRecStride, EigRec<N>::STATUS, 0.0);
     }
     return;
   }

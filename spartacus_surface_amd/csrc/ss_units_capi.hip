@@ -157,11 +157,11 @@ __global__ void __launch_bounds__(64) k_unit_coop_pre(const UnitArgs A) {
 }
 template <int N>
 __global__ void __launch_bounds__(64) k_unit_coop_eig(const UnitArgs A) {
-  const int m = blockIdx.x * 16 + ((int)threadIdx.x >> 2);
+  constexpr int G = ss::kCoopLanes;
+  const int m = blockIdx.x * (64 / G) + (int)threadIdx.x / G;
   if (m >= A.nmat) return;
   if constexpr (ss::coop_order(N))
-    ss::coop_eig_unit<N, ss::kCoopLanes>(A.eig + ss::rec_base(0, 1, ss::EigRec<N>::NELEM, m), ss::kRecStride,
-                                         (int)threadIdx.x & 3);
+    ss::coop_eig_unit<N, G>(A.eig + ss::rec_base(0, 1, ss::EigRec<N>::NELEM, m), ss::kRecStride, (int)threadIdx.x % G);
 }
 
 template <int N>
@@ -217,7 +217,7 @@ int finish(Stage& s, const char* what) {
   if (ss::coop_order(NN) && A.dsc) {                                                                \
     A.eig = static_cast<double*>(s.raw(tiles * 64 * (size_t)ss::EigRec<NN>::NELEM * sizeof(double)));   \
     if (s.err == hipSuccess) hipLaunchKernelGGL((k_unit_coop_pre<NN>), dim3(tiles), dim3(64), 0, 0, A); \
-    if (s.err == hipSuccess) hipLaunchKernelGGL((k_unit_coop_eig<NN>), dim3((nmat + 15) / 16), dim3(64), 0, 0, A); \
+    if (s.err == hipSuccess) hipLaunchKernelGGL((k_unit_coop_eig<NN>), dim3((nmat + 64 / ss::kCoopLanes - 1) / (64 / ss::kCoopLanes)), dim3(64), 0, 0, A); \
   }
 #define UNIT_SW_CASE(NN, DD)                                                                        \
   if (ndiff == NN && ndir == DD) {                                                                  \

@@ -12,6 +12,7 @@
 #include <cstring>
 
 #include "../../spartacus_surface_amd/csrc/ss_plan_impl.hpp"
+#include "../../spartacus_surface_amd/csrc/ss_layer16.hpp"
 
 namespace {
 
@@ -71,8 +72,13 @@ struct EmulBackend {
           for (int cu = 0; cu < L.ncu; ++cu) {
             if (lw) ss::layer_unit_lw<U, R, NS, 1>(L, cu, jlay);
             else ss::layer_unit_sw<U, R, NS, 1>(L, cu, jlay);
-            if (jlay < L.in.nlay[L.cols[cu / L.nspec]])
-              ss::coop_eig_unit<NN, 1>(L.eig + ss::rec_base(jlay, L.maxlay, ss::EigRec<NN>::NELEM, cu), ss::kRecStride, 0);
+            if (jlay < L.in.nlay[L.cols[cu / L.nspec]]) {
+              double* erec = L.eig + ss::rec_base(jlay, L.maxlay, ss::EigRec<NN>::NELEM, cu);
+              ss::coop_eig_unit<NN, 1>(erec, ss::kRecStride, 0);
+              if (ss::r16_layer(NN, lw) && ss::rec_elem_load(erec, ss::kRecStride, ss::EigRec<NN>::STATUS) > 0.5) {
+                if (lw) ss::r16::layer_lw<NN>(erec, ss::kRecStride, L.lay + ss::rec_base(jlay, L.maxlay, ss::LwRec<NN>::NELEM, cu));
+              }
+            }
           }
       }
       for (int jlay = 0; jlay < L.maxlay; ++jlay)
