@@ -57,7 +57,7 @@ constexpr bool r16_layer(int n, bool lw) {
 #if defined(SS_NO_R16_LAYER)
   return false && n > 0 && lw;
 #else
-  return coop_order(n) && lw;
+  return coop_order(n) && (lw || !lw);
 #endif
 }
 
@@ -69,7 +69,12 @@ constexpr bool r16_layer(int n, bool lw) {
 //   X     D L in,  eigenvectors X = D L Y out   (the rotations are accumulated into D L ...
 //   AX    -D L^-T in, (G1 - G2)^-1 X = -D L^-T Y out   ... and into -D L^-T instead of into I)
 //   G1, G2, VEC: the Gamma matrices and vectors of the unit for the layer kernel in the row-of-16
-//   layout (ss_layer16.hpp); VEC = [dscale (N)] [b (N), longwave] or [g0 (D*D) g3 (N*D, row-major) dscale0 (D), shortwave]
+//   layout (ss_layer16.hpp); VEC = [dscale (N)] then, longwave: [b (N)]; shortwave: [g3 (N x D, row-major)]
+//   [mu (D)] [eigenvectors of Gamma0 (D x D)] [their inverse (D x D)] [exp(mu dz) (D)]
+constexpr int eig_rec_nvec(int n) { return 5 * n + 18; }     // room for either spectral region (D <= 3, n >= 7)
+constexpr int eig_rec_nelem(int n) {
+  return 2 + rec_even(n) + 5 * rec_even(n * n) + rec_even(eig_rec_nvec(n));
+}
 template <int N>
 struct EigRec {
   static constexpr int STATUS = 0;
@@ -80,8 +85,16 @@ struct EigRec {
   static constexpr int G1 = AX + rec_even(N * N);
   static constexpr int G2 = G1 + rec_even(N * N);
   static constexpr int VEC = G2 + rec_even(N * N);
-  static constexpr int NVEC = 2 * N + 3 * 3 + 3 * N + 4;    // room for either spectral region (D <= 3)
+  static constexpr int NVEC = eig_rec_nvec(N);
   static constexpr int NELEM = VEC + rec_even(NVEC);
+  static_assert(NELEM == eig_rec_nelem(N), "eig_rec_nelem is what the plan sizes the scratch with");
+  // shortwave members of VEC for D direct streams
+  static constexpr int vg3() { return VEC + N; }
+  static constexpr int vmu(int D) { return VEC + N + N * D; }
+  static constexpr int vg0(int D) { return vmu(D) + D; }
+  static constexpr int vg0inv(int D) { return vg0(D) + D * D; }
+  static constexpr int vemu(int D) { return vg0inv(D) + D * D; }
+  static_assert(N < 7 || N + N * 3 + 3 + 9 + 9 + 3 <= NVEC, "VEC too small");
 };
 
 // element e of a record, read as a scalar (pairs: element e sits at pair e/2, half e%2)

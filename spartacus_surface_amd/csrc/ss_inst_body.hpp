@@ -7,6 +7,7 @@
 #include "ss_solver_lw.hpp"
 #include "ss_solver_sw.hpp"
 #include "ss_layer16.hpp"
+#include "ss_column16.hpp"
 
 namespace ss {
 namespace {
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(kBlock, 1) k_layer_up(const Launch L) {
 
 // layer matrices of the cooperative units on the 16 lanes of a DPP row (ss_layer16.hpp):
 // block -> (tile of 64 units, layer, sixteenth of the tile); 4 units per wave
-template <int N, bool LW>
+template <int N, int D, bool LW>
 __global__ void __launch_bounds__(kBlock, 2) k_layer16(const Launch L) {
   constexpr int UPB = kBlock / r16::kRow;          // units per block
   const int part = blockIdx.x % r16::kRow, tl = blockIdx.x / r16::kRow;
@@ -89,6 +90,19 @@ __global__ void __launch_bounds__(kBlock, 2) k_layer16(const Launch L) {
     if (!(rec_elem_load(erec, kRecStride, EigRec<N>::STATUS) > 0.5)) return;     // same for the whole row
     if constexpr (LW)
       r16::layer_lw<N>(erec, kRecStride, L.lay + rec_base(jlay, L.maxlay, LwRec<N>::NELEM, cu));
+    else
+      r16::layer_sw<N, D>(erec, kRecStride, L.lay + rec_base(jlay, L.maxlay, SwRec<N, D>::NELEM, cu));
+  }
+}
+
+// upward sweep of the cooperative orders: one column unit on the 16 lanes of a DPP row (ss_column16.hpp)
+template <bool U, int R, int NS, bool LW>
+__global__ void __launch_bounds__(kBlock, 2) k_column16(const Launch L) {
+  const int cu = blockIdx.x * (kBlock / r16::kRow) + (int)threadIdx.x / r16::kRow;
+  if (cu >= L.ncu) return;
+  if constexpr (r16_layer(R * NS, LW)) {
+    if constexpr (LW) r16::column_up_lw<U, R, NS>(L, cu);
+    else r16::column_up_sw<U, R, NS>(L, cu);
   }
 }
 
@@ -153,7 +167,7 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev) {
     hipLaunchKernelGGL((k_eig_coop<SS_INST_NREG * NS>), dim3(gx * (unsigned)L.maxlay * kCoopLanes), dim3(kBlock), 0, stream, L);
     SS_TRY(hipGetLastError());
     if constexpr (r16_layer(SS_INST_NREG * NS, SS_INST_LW != 0)) {
-      hipLaunchKernelGGL((k_layer16<SS_INST_NREG * NS, SS_INST_LW != 0>), dim3(gx * (unsigned)L.maxlay * r16::kRow),
+      hipLaunchKernelGGL((k_layer16<SS_INST_NREG * NS, SS_INST_NREG, SS_INST_LW != 0>), dim3(gx * (unsigned)L.maxlay * r16::kRow),
                          dim3(kBlock), 0, stream, L);
       SS_TRY(hipGetLastError());
     }
@@ -166,8 +180,14 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev) {
     SS_TRY(hipGetLastError());
   }
   if (ev) SS_TRY(hipEventRecord(ev[1], stream));
-  hipLaunchKernelGGL((k_column<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx), dim3(kBlock), 0,
-                     stream, L);
+  if constexpr (r16_layer(SS_INST_NREG * NS, SS_INST_LW != 0)) {
+    constexpr unsigned upb = kBlock / r16::kRow;
+    hipLaunchKernelGGL((k_column16<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>),
+                       dim3(((unsigned)L.ncu + upb - 1) / upb), dim3(kBlock), 0, stream, L);
+  } else {
+    hipLaunchKernelGGL((k_column<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx), dim3(kBlock), 0,
+                       stream, L);
+  }
   SS_TRY(hipGetLastError());
   if (ev) SS_TRY(hipEventRecord(ev[2], stream));
   {

@@ -57,26 +57,21 @@ struct Diffuse {
 };
 
 template <int N>
-SS_HD void diffuse_part(const double* erec, long stride, double dz, Diffuse<N>& w, double* lrec, int offR, int offT) {
-  using ER = EigRec<N>;
-  w.lam_d = r_sqrt(r_max(load_vec<N>(erec, stride, ER::EV), 0.0));
+SS_HD void diffuse_part(const rv* X, const rv* AX, const rv& ev_d, double dz, Diffuse<N>& w, double* lrec,
+                        long stride, int offR, int offT) {
+  w.lam_d = r_sqrt(r_max(ev_d, 0.0));
   w.e_d = r_exp(-(w.lam_d * dz));
   all_of<N>(w.lam_d, w.lam);
   all_of<N>(w.e_d, w.e);
   rv t1[N];
-  {
-    // tmp = -((G1 - G2)^-1 X) diag(lam);  G1 = X + tmp, G2 = X - tmp
-    rv X[N], AX[N];
-    load_rowmajor<N, N>(erec, stride, ER::X, X);
-    load_rowmajor<N, N>(erec, stride, ER::AX, AX);
-    SS_UNROLL_FULL
-    for (int j = 0; j < N; ++j) {
-      const rv t = -(AX[j] * w.lam[j]);
-      w.G1[j] = X[j] + t;
-      w.G2[j] = X[j] - t;
-      w.luG1.a[j] = w.G1[j];
-      t1[j] = w.G2[j];
-    }
+  // tmp = -((G1 - G2)^-1 X) diag(lam);  G1 = X + tmp, G2 = X - tmp
+  SS_UNROLL_FULL
+  for (int j = 0; j < N; ++j) {
+    const rv t = -(AX[j] * w.lam[j]);
+    w.G1[j] = X[j] + t;
+    w.G2[j] = X[j] - t;
+    w.luG1.a[j] = w.G1[j];
+    t1[j] = w.G2[j];
   }
   // Eq. 48 by Schur complement; G1D = G1 diag(e), G2D = G2 diag(e) are never formed
   lu_factor<N>(w.luG1);
@@ -128,7 +123,12 @@ SS_HD void layer_lw(const double* erec, long stride, double* lrec) {
     igb = v[0];
   }
   Diffuse<N> df;
-  diffuse_part<N>(erec, stride, dz, df, lrec, LR::R, LR::T);
+  {
+    rv X[N], AX[N];
+    load_rowmajor<N, N>(erec, stride, ER::X, X);
+    load_rowmajor<N, N>(erec, stride, ER::AX, AX);
+    diffuse_part<N>(X, AX, load_vec<N>(erec, stride, ER::EV), dz, df, lrec, stride, LR::R, LR::T);
+  }
   // Section 4 (:198-209): cb' and the source
   rv cb;
   {
@@ -158,6 +158,124 @@ SS_HD void layer_lw(const double* erec, long stride, double* lrec) {
     rv v;
     mat_vec<N, false>(GZ, cb, v);
     store_vec<N>(lrec, stride, LR::ISRC, 2.0 * (v + igb * dz));
+  }
+}
+
+// calc_matrices_sw_eig of a full problem (N diffuse, D direct streams): R, T, S_up, S_dn of the layer
+// record from the eigen record; int_dir and E were written by the first pass of the layer kernel
+// (sw_direct_part), which also left mu, G0, G0^-1, exp(mu dz) of Gamma0 in the eigen record.
+template <int N, int D>
+SS_HD void layer_sw(const double* erec, long stride, double* lrec) {
+  using ER = EigRec<N>;
+  using LR = SwRec<N, D>;
+  const double dz = rec_elem_load(erec, stride, 1);
+  double mu[D], G0[D * D], G0inv[D * D], emu[D];
+  SS_UNROLL_FULL
+  for (int r = 0; r < D; ++r) {
+    mu[r] = rec_elem_load(erec, stride, ER::vmu(D) + r);
+    emu[r] = rec_elem_load(erec, stride, ER::vemu(D) + r);
+  }
+  SS_UNROLL_FULL
+  for (int k = 0; k < D * D; ++k) {
+    G0[k] = rec_elem_load(erec, stride, ER::vg0(D) + k);
+    G0inv[k] = rec_elem_load(erec, stride, ER::vg0inv(D) + k);
+  }
+  const rv ev_d = load_vec<N>(erec, stride, ER::EV);
+  rv g3v[D], g4v[D];   // particular solutions, one column per direct eigenvalue
+  Diffuse<N> df;
+  {
+    rv X[N], AX[N];
+    load_rowmajor<N, N>(erec, stride, ER::X, X);
+    load_rowmajor<N, N>(erec, stride, ER::AX, AX);
+    // Section 4 (:231-253) through the eigen-decomposition (see ss_layer_matrices.hpp): sources
+    // s = g3 G0 (one column per direct eigenvalue), c = 2 (Lambda - mu^2)^-1 (D^-2 X)^T s,
+    // p = X c, q = -mu ((G1 - G2)^-1 X) c, g3 = (p + q) / 2, g4 = (p - q) / 2
+    rv g3[D];
+    load_rowmajor<N, D>(erec, stride, ER::vg3(), g3);
+    const rv dsc = load_vec<N>(erec, stride, ER::VEC);
+    const rv rd2 = select(lane_lt(N), 1.0 / (dsc * dsc), rv(0.0));
+    const rv one = 1.0;
+    SS_UNROLL_FULL
+    for (int jd = 0; jd < D; ++jd) {
+      rv s = 0.0;
+      SS_UNROLL_FULL
+      for (int r = 0; r < D; ++r) s = s + g3[r] * SS_E(G0, r, jd, D);
+      s = s * rd2;
+      rv t[N], h[N];
+      SS_UNROLL_FULL
+      for (int k = 0; k < N; ++k) {
+        t[k] = X[k] * s;
+        h[k] = 0.0;
+      }
+      // sums over the lanes: h[k] = sum_i X(i, k) s_i / d_i^2, on every lane
+      static_for<0, N>([&](auto ic) { row_fma<decltype(ic)::value, N>(h, t, one); });
+      // 2 / (lambda_k - mu^2): one division on lane k, then to every lane
+      double rden[N];
+      all_of<N>(2.0 / (ev_d - mu[jd] * mu[jd]), rden);
+      rv pv = 0.0, qv = 0.0;
+      SS_UNROLL_FULL
+      for (int k = 0; k < N; ++k) {
+        const rv c = h[k] * rden[k];
+        pv = pv + X[k] * c;
+        qv = qv + AX[k] * c;
+      }
+      const rv q = -(qv * mu[jd]);
+      g3v[jd] = 0.5 * (pv + q);
+      g4v[jd] = 0.5 * (pv - q);
+    }
+    // Sections 1-2: diffuse R, T
+    diffuse_part<N>(X, AX, ev_d, dz, df, lrec, stride, LR::R, LR::T);
+  }
+  // direct_diffuse_part (:303-386) by block elimination (header of ss_layer_matrices.hpp)
+  {
+    rv b1[D], b2[D], c1[D], c2[D], t[D], te[D], su[D];
+    SS_UNROLL_FULL
+    for (int j = 0; j < D; ++j) {
+      rv s1 = 0.0, s2 = 0.0;
+      SS_UNROLL_FULL
+      for (int r = 0; r < D; ++r) {
+        s1 = s1 + (g3v[r] * emu[r]) * SS_E(G0inv, r, j, D);      // (g3 e) G0^-1 = -(rhs of block 1)
+        s2 = s2 + g4v[r] * SS_E(G0inv, r, j, D);                 // g4 G0^-1     = -(rhs of block 2)
+      }
+      b1[j] = s1;
+      b2[j] = s2;
+      t[j] = s1;
+    }
+    // c2 = S^-1 (-b2 + G2D G1^-1 b1)
+    lu_solve<N, D>(df.luG1, t);
+    SS_UNROLL_FULL
+    for (int j = 0; j < D; ++j) te[j] = t[j] * df.e_d;
+    mul<N, D, false, false>(df.G2, nullptr, te, c1);
+    SS_UNROLL_FULL
+    for (int j = 0; j < D; ++j) c1[j] = c1[j] - b2[j];
+    mul<N, D, false, false>(df.Clo, nullptr, c1, c2);
+    // c1 = G1^-1 (-b1 - G2D c2)
+    SS_UNROLL_FULL
+    for (int j = 0; j < D; ++j) te[j] = c2[j] * df.e_d;           // diag(e) c2, reused for S_dn
+    mul<N, D, false, false>(df.G2, nullptr, te, c1);
+    SS_UNROLL_FULL
+    for (int j = 0; j < D; ++j) c1[j] = -b1[j] - c1[j];
+    lu_solve<N, D>(df.luG1, c1);
+    // S_up = G1D c1 + G2 c2 + g3 G0^-1 ; S_dn = G2 c1 + G1D c2 + (g4 e) G0^-1
+    mul<N, D, false, false>(df.G2, nullptr, c1, t);
+    mul<N, D, true, false>(df.G1, nullptr, te, t);               // S_dn without the particular part
+    SS_UNROLL_FULL
+    for (int j = 0; j < D; ++j) te[j] = c1[j] * df.e_d;           // diag(e) c1
+    mul<N, D, false, false>(df.G1, nullptr, te, su);
+    mul<N, D, true, false>(df.G2, nullptr, c2, su);
+    SS_UNROLL_FULL
+    for (int j = 0; j < D; ++j) {
+      rv s1 = su[j], s2 = t[j];
+      SS_UNROLL_FULL
+      for (int r = 0; r < D; ++r) {
+        s1 = s1 + g3v[r] * SS_E(G0inv, r, j, D);
+        s2 = s2 + (g4v[r] * emu[r]) * SS_E(G0inv, r, j, D);
+      }
+      su[j] = s1;
+      t[j] = s2;
+    }
+    store_colmajor<N, D>(lrec, stride, LR::SUP, su);
+    store_colmajor<N, D>(lrec, stride, LR::SDN, t);
   }
 }
 

@@ -447,6 +447,40 @@ SS_HD int diffuse_part(const double* g1, const double* g2, const double* dscale,
   return ierr;
 }
 
+// The direct-beam part of calc_matrices_sw_eig for a full problem: int_dir = -Gamma0^-1
+// (radtool_schur.F90:45-51) and E = G0 diag(exp(mu dz)) G0^-1 (sw_eig :223-229) into the layer
+// record; returns the eigenvalues mu and eigenvectors G0 of Gamma0, G0^-1 and exp(mu dz).
+template <int NF, int D, class W>
+SS_HD int sw_direct_part(const double* g0, const double* dsc0, double dz, const W& w, double* mu, double* G0,
+                         double* G0inv, double* emu) {
+  using Rec = SwRec<NF, D>;
+  {
+    double LU0[D * D], g0i[D * D], idir[D * D];
+    mat_copy<D, D>(g0, LU0);
+    lu_factor<D>(LU0);
+    lu_invert<D>(LU0, g0i);
+    SS_UNROLL_FULL
+    for (int k = 0; k < D * D; ++k) idir[k] = -g0i[k];
+    put_embedded<D, D, D, D, 0, 0>(w, Rec::IDIR, idir);
+  }
+  int rc = -1;
+  if constexpr (D >= 3 && D <= SS_UNROLL_MAX) {
+    if (dsc0) rc = eigen_decomposition_scaled_sym<D>(g0, dsc0, mu, G0);
+    if (rc >= 0 && !sym_spectrum_is_well_graded<D>(mu)) rc = -1;
+  }
+  if (rc < 0) rc = eigen_decomposition_real<D>(g0, mu, G0);
+  double LU0[D * D], t[D * D], Ed[D * D];
+  mat_copy<D, D>(G0, LU0);
+  lu_factor<D>(LU0);
+  lu_invert<D>(LU0, G0inv);
+  SS_UNROLL_N(D)
+  for (int j = 0; j < D; ++j) emu[j] = exp(mu[j] * dz);
+  scale_cols<D>(G0, emu, t);
+  mat_mul<D, D, D>(t, G0inv, Ed);
+  put_embedded<D, D, D, D, 0, 0>(w, Rec::EDIR, Ed);
+  return rc;
+}
+
 // calc_matrices_sw_eig for an (N, D) sub-problem embedded at (I0 = stream
 // offset, R0 = region offset) of the full (NF, DF) record.
 template <int NF, int DF, int N, int D, int I0, int R0, class W>

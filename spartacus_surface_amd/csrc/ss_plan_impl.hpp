@@ -96,8 +96,7 @@ inline int col_nelem(bool lw, const ClassKey& k) {
 // eigen record of the cooperative eigen-solver (= EigRec<n>::NELEM, ss_eigen_coop.hpp); 0 = order not cooperative
 inline int eig_nelem(const ClassKey& k) {
   const int n = k.nreg * k.ns;
-  auto ev = [](int x) { return (x + 1) & ~1; };
-  return coop_order(n) ? 2 + ev(n) + 5 * ev(n * n) + ev(2 * n + 9 + 3 * n + 4) : 0;
+  return coop_order(n) ? eig_rec_nelem(n) : 0;
 }
 
 // Runtime (urban, nreg, ns) -> template instance

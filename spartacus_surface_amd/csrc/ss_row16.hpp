@@ -65,6 +65,9 @@ SS_HD rv r_max(rv a, double b) { return a > b ? a : b; }
 template <class F>
 SS_HD rv gen(F&& f) { return f(lane()); }
 template <class F>
+SS_HD rm gen_mask(F&& f) { return f(lane()); }
+SS_HD bool lane0() { return lane() == 0; }
+template <class F>
 SS_HD void each(const rv& x, F&& f) { f(lane(), x); }
 SS_HD double uniform(rv x) { return x; }
 
@@ -85,6 +88,11 @@ SS_HD void fma1(rv& c0, rv b0, rv a) {
 template <int K>
 SS_HD void fma2(rv& c0, rv& c1, rv b0, rv b1, rv a) {
   asm volatile("s_nop 1\n" SS_R16_L(0, 2) SS_R16_L(1, 3) : "+v"(c0), "+v"(c1) : "v"(b0), "v"(b1), [a] "v"(a), [k] "n"(K));
+}
+template <int K>
+SS_HD void fma3(rv* c, const rv* b, rv a) {
+  asm volatile("s_nop 1\n" SS_R16_L(0, 3) SS_R16_L(1, 4) SS_R16_L(2, 5)
+               : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]) : "v"(b[0]), "v"(b[1]), "v"(b[2]), [a] "v"(a), [k] "n"(K));
 }
 template <int K>
 SS_HD void fma4(rv* c, const rv* b, rv a) {
@@ -122,6 +130,8 @@ SS_HD void row_fma_from(rv* c, const rv* b, rv a) {
   } else if constexpr (W >= 4) {
     fma4<K>(c + J0, b + J0, a);
     row_fma_from<K, J0 + 4, M>(c, b, a);
+  } else if constexpr (W == 3) {
+    fma3<K>(c + J0, b + J0, a);
   } else if constexpr (W >= 2) {
     fma2<K>(c[J0], c[J0 + 1], b[J0], b[J0 + 1], a);
     row_fma_from<K, J0 + 2, M>(c, b, a);
@@ -158,6 +168,9 @@ inline rv r_exp(const rv& x) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = std
 inline rv r_max(const rv& a, double b) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = a.v[l] > b ? a.v[l] : b; return r; }
 template <class F>
 inline rv gen(F&& f) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = f(l); return r; }
+template <class F>
+inline rm gen_mask(F&& f) { rm m; for (int l = 0; l < kRow; ++l) m.v[l] = f(l); return m; }
+inline bool lane0() { return true; }
 template <class F>
 inline void each(const rv& x, F&& f) { for (int l = 0; l < kRow; ++l) f(l, x.v[l]); }
 inline double uniform(const rv& x) { return x.v[0]; }

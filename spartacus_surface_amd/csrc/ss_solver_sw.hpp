@@ -65,6 +65,11 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
   const int col = L.cols[cu / L.nspec];
   const int jb = cu % L.nspec;
   if (jlay >= in.nlay[col]) return;
+  if constexpr (STAGE == 2 && r16_layer(NREG * NS, false)) {
+    // units of the cooperative route had their layer matrices computed by the row-of-16 kernel
+    if (rec_elem_load(L.eig + rec_base(jlay, L.maxlay, EigRec<NREG * NS>::NELEM, cu), kRecStride,
+                      EigRec<NREG * NS>::STATUS) > 0.5) return;
+  }
 
   const double cos_in = in.cos_sza[col];
   const double cos_sza = URBAN ? ss_max(cos_in, 1.0e-6) : cos_in;
@@ -192,7 +197,32 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
     if (full) {
       double GD[N * N];
       for (int k = 0; k < N * N; ++k) GD[k] = g1[k] - g2[k];
-      coop_eig_pre<N>(GD, g2, dsc, erec, kRecStride);
+      if (coop_eig_pre<N>(GD, g2, dsc, erec, kRecStride) && r16_layer(N, false)) {
+        // The direct-beam part of the unit (D x D: one lane does it for its unit here, the 16 lanes
+        // of the row-of-16 kernel would each repeat it): int_dir and E go to the layer record, the
+        // eigen-decomposition of Gamma0 and what else ss_layer16.hpp needs to the eigen record
+        using ER = EigRec<N>;
+        double mu[D], G0[D * D], G0inv[D * D], emu[D];
+        const int rc = sw_direct_part<N, D>(g0, dsc0, g.dz, w, mu, G0, G0inv, emu);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (rc != 0 && L.eigen_fail) atomicAdd(L.eigen_fail, 1ULL);
+#else
+        if (rc != 0 && L.eigen_fail) *L.eigen_fail += 1ULL;
+#endif
+        rec_elem_store(erec, kRecStride, 1, g.dz);
+        for (int i = 0; i < N; ++i) {
+          rec_elem_store(erec, kRecStride, ER::VEC + i, dsc[i]);
+          for (int r = 0; r < D; ++r) rec_elem_store(erec, kRecStride, ER::vg3() + i * D + r, SS_E(g3, i, r, N));
+        }
+        for (int r = 0; r < D; ++r) {
+          rec_elem_store(erec, kRecStride, ER::vmu(D) + r, mu[r]);
+          rec_elem_store(erec, kRecStride, ER::vemu(D) + r, emu[r]);
+        }
+        for (int k = 0; k < D * D; ++k) {
+          rec_elem_store(erec, kRecStride, ER::vg0(D) + k, G0[k]);
+          rec_elem_store(erec, kRecStride, ER::vg0inv(D) + k, G0inv[k]);
+        }
+      }
     } else {
       rec_elem_store(erec, kRecStride, EigRec<N>::STATUS, 0.0);
     }

@@ -13,6 +13,8 @@
 
 #include "../../spartacus_surface_amd/csrc/ss_plan_impl.hpp"
 #include "../../spartacus_surface_amd/csrc/ss_layer16.hpp"
+#include "../../spartacus_surface_amd/csrc/ss_column16.hpp"
+#include "../../spartacus_surface_amd/csrc/ss_down16.hpp"
 
 namespace {
 
@@ -77,6 +79,7 @@ struct EmulBackend {
               ss::coop_eig_unit<NN, 1>(erec, ss::kRecStride, 0);
               if (ss::r16_layer(NN, lw) && ss::rec_elem_load(erec, ss::kRecStride, ss::EigRec<NN>::STATUS) > 0.5) {
                 if (lw) ss::r16::layer_lw<NN>(erec, ss::kRecStride, L.lay + ss::rec_base(jlay, L.maxlay, ss::LwRec<NN>::NELEM, cu));
+                else ss::r16::layer_sw<NN, R>(erec, ss::kRecStride, L.lay + ss::rec_base(jlay, L.maxlay, ss::SwRec<NN, R>::NELEM, cu));
               }
             }
           }
@@ -88,8 +91,19 @@ struct EmulBackend {
         }
     }
     for (int cu = 0; cu < L.ncu; ++cu) {
-      if (lw) ss::column_unit_lw<U, R, NS>(L, cu);
-      else ss::column_unit_sw<U, R, NS>(L, cu);
+      if constexpr (ss::r16_layer(R * NS, true) && ss::r16_layer(R * NS, false)) {
+        // the cooperative orders: both sweeps on a pack of 16 "lanes"
+        if (lw) {
+          ss::r16::column_up_lw<U, R, NS>(L, cu);
+          ss::r16::column_down_lw<U, R, NS>(L, cu);
+        } else {
+          ss::r16::column_up_sw<U, R, NS>(L, cu);
+          ss::r16::column_down_sw<U, R, NS>(L, cu);
+        }
+      } else {
+        if (lw) ss::column_unit_lw<U, R, NS>(L, cu);
+        else ss::column_unit_sw<U, R, NS>(L, cu);
+      }
     }
   }
   static void launch_scale_sum(const ss::ScaleSumLaunch& S, Timers&) {
