@@ -199,6 +199,11 @@ struct Launch {
   FluxDev flux_b;        // sw_norm_diff / lw_norm
   unsigned long long* eigen_fail;   // count of non-converged eigenproblems
 };
+// Counter slot (of the buffer behind Launch::eigen_fail, zeroed at the start of every solve) that the
+// first pass of the layer kernel of the cooperative orders sets when it meets a unit the cooperative
+// route does not take (a sub-problem, or no symmetric structure): as long as it is zero the second
+// pass (one lane per unit) has nothing to do and its blocks leave at once.
+constexpr int kSlotOneLaneUnits = 31;
 
 // In-kernel section stamps (profiling builds only, -DSS_STAMPS): lane 0 of every
 // wave adds the s_memtime ticks spent since the previous stamp to counter k of

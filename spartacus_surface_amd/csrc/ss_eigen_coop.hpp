@@ -36,12 +36,14 @@
 
 namespace ss {
 
-// lanes per problem of the Jacobi kernel: 4 (three matrices of N^2 / 4 doubles per lane fit its
-// registers; 1.8 ms per 500 000 12 x 12 problems against 2.8 ms with 8)
-#ifndef SS_COOP_LANES
-#define SS_COOP_LANES 4
+// lanes per problem of the Jacobi kernel: 2 up to order 12 (W and Y are 2 x 72 doubles per lane: the
+// update of a rotation is lane-local, the angle is computed once per 2 lanes instead of once per 4;
+// 0.72 ms per 200 000 12 x 12 problems against 1.13 ms with 4 lanes), 4 above (registers)
+#ifdef SS_COOP_LANES
+constexpr int coop_lanes(int) { return SS_COOP_LANES; }
+#else
+constexpr int coop_lanes(int n) { return n <= 12 ? 2 : 4; }
 #endif
-constexpr int kCoopLanes = SS_COOP_LANES;
 // which spectral regions run the layer matrices of the cooperative units on the 16 lanes of a DPP row (ss_layer16.hpp)
 constexpr bool r16_layer(int n, bool lw);
 constexpr int kCoopMaxOrder = 16;
@@ -65,9 +67,9 @@ constexpr bool r16_layer(int n, bool lw) {
 // matrices ROW-major, so that a lane of the cooperative kernels loads its rows):
 //   [0] status (1 = a cooperative unit, 0 = not), [1] layer thickness dz,
 //   EV    squared singular values (out)
-//   W     W = F^T L (in)
-//   X     D L in,  eigenvectors X = D L Y out   (the rotations are accumulated into D L ...
-//   AX    -D L^-T in, (G1 - G2)^-1 X = -D L^-T Y out   ... and into -D L^-T instead of into I)
+//   W     W = F^T L in, its right singular vectors Y out
+//   X     D L:      the eigenvectors are X = (D L) Y
+//   AX    -D L^-T:  (G1 - G2)^-1 X = (-D L^-T) Y
 //   G1, G2, VEC: the Gamma matrices and vectors of the unit for the layer kernel in the row-of-16
 //   layout (ss_layer16.hpp); VEC = [dscale (N)] then, longwave: [b (N)]; shortwave: [g3 (N x D, row-major)]
 //   [mu (D)] [eigenvectors of Gamma0 (D x D)] [their inverse (D x D)] [exp(mu dz) (D)]
@@ -106,7 +108,36 @@ SS_HD void rec_elem_store(double* rec, long stride, int e, double v) {
   rec[(long)(e & ~1) * stride + (e & 1)] = v;
 }
 
-// ---- pass 1 of the layer kernel: W = F^T L from the Gamma matrices (one lane per problem) ----
+// ---- pass 1 of the layer kernel, one lane per problem: is the structure there? ----
+// dscale = D: both D^-1 (G1 - G2) D and D^-1 G2 D must be symmetric.  Returns the
+// largest element of the two scaled matrices in "size" (the scale of the pivot test of the Cholesky
+// factorisations, which the row-of-16 kernel does: r16::eig_pre, ss_layer16.hpp).
+template <int N>
+SS_HD bool coop_eig_check(const double* G1, const double* G2, const double* dscale, double& size) {
+  bool ok = true;
+  double rd[N];
+  for (int i = 0; i < N; ++i) {
+    if (!(dscale[i] > 0.0)) ok = false;
+    rd[i] = 1.0 / (ok ? dscale[i] : 1.0);
+  }
+  double asym = 0.0;
+  size = 0.0;
+  for (int j = 0; j < N; ++j) {
+    for (int i = j; i < N; ++i) {
+      const double c_ij = -(SS_E(G1, i, j, N) - SS_E(G2, i, j, N)) * (dscale[j] * rd[i]);
+      const double s_ij = SS_E(G2, i, j, N) * (dscale[j] * rd[i]);
+      if (i != j) {
+        const double c_ji = -(SS_E(G1, j, i, N) - SS_E(G2, j, i, N)) * (dscale[i] * rd[j]);
+        const double s_ji = SS_E(G2, j, i, N) * (dscale[i] * rd[j]);
+        asym = ss_max(asym, ss_max(fabs(c_ij - c_ji), fabs(s_ij - s_ji)));
+      }
+      size = ss_max(size, ss_max(fabs(c_ij), fabs(s_ij)));
+    }
+  }
+  return ok && (asym <= 1.0e-10 * size);
+}
+
+// ---- the same plus the factors, one lane per problem (kernel-level entries, builds without the row-of-16 kernels) ----
 // A = G1 - G2, g2 = G2, dscale = D.  Returns false (status 0) when the structure is not there
 // numerically (not symmetric after scaling, not positive definite): the second pass then uses
 // the general solver for this unit.
@@ -183,19 +214,27 @@ SS_HD bool coop_eig_pre(const double* A, const double* G2, const double* dscale,
 
 
 // ---- pass 2 of the layer kernel: eigenvalues / vectors from the record ----
-// Same outputs as eigen_decomposition_gamma_sym: eigenvalue, eigenvector X = D L Y, ainv_x =
-// A^-1 X = -D L^-T Y.  Returns -1 when the record says the unit is not a cooperative one.
+// Same outputs as eigen_decomposition_gamma_sym: eigenvalue, eigenvector X = (D L) Y, ainv_x =
+// A^-1 X = (-D L^-T) Y.  Returns -1 when the record says the unit is not a cooperative one.
+// (One lane per problem: the kernel-level entries and builds without the row-of-16 kernels; the
+// production path forms the two products in ss_layer16.hpp.)
 template <int N>
 SS_HD int coop_eig_post(const double* A, const double* dscale, const double* rec, long stride,
                         double* eigenvalue, double* eigenvector, double* ainv_x) {
   (void)A; (void)dscale;
   if (!(rec_elem_load(rec, stride, EigRec<N>::STATUS) > 0.5)) return -1;
   for (int j = 0; j < N; ++j) eigenvalue[j] = rec_elem_load(rec, stride, EigRec<N>::EV + j);
-  for (int i = 0; i < N; ++i)
-    for (int j = 0; j < N; ++j) {
-      SS_E(eigenvector, i, j, N) = rec_elem_load(rec, stride, EigRec<N>::X + i * N + j);
-      SS_E(ainv_x, i, j, N) = rec_elem_load(rec, stride, EigRec<N>::AX + i * N + j);
+  for (int j = 0; j < N; ++j) {
+    double y[N];
+    for (int k = 0; k < N; ++k) y[k] = rec_elem_load(rec, stride, EigRec<N>::W + k * N + j);   // Y(k, j)
+    for (int i = 0; i < N; ++i) {
+      double s = 0.0, t = 0.0;
+      for (int k = 0; k <= i; ++k) s += rec_elem_load(rec, stride, EigRec<N>::X + i * N + k) * y[k];
+      for (int k = i; k < N; ++k) t += rec_elem_load(rec, stride, EigRec<N>::AX + i * N + k) * y[k];
+      SS_E(eigenvector, i, j, N) = s;
+      SS_E(ainv_x, i, j, N) = t;
     }
+  }
   return 0;
 }
 
@@ -208,25 +247,49 @@ __device__ __forceinline__ double group_sum(double x) {
   for (int m = 1; m < G; m <<= 1) x += __shfl_xor(x, m);
   return x;
 }
+// 1 / x and sqrt(x), 1 / sqrt(x) from the hardware estimates and two Newton / Goldschmidt steps
+// (relative error of a few 1e-16, no denormal or division-by-zero fix-up: the arguments here are sums of
+// squares of a positive definite problem).  A rotation built from them is orthogonal to rounding
+// whatever the error of its angle, which only costs convergence speed.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return fma(r, fma(-x, r, 1.0), r);
+}
+__device__ __forceinline__ void fast_sqrt_rsqrt(double x, double& s, double& rs) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double e = fma(-h, g, 0.5);
+  g = fma(g, e, g);
+  h = fma(h, e, h);
+  e = fma(-h, g, 0.5);
+  s = fma(g, e, g);
+  rs = 2.0 * fma(h, e, h);
+}
+#else
+inline double fast_rcp(double x) { return 1.0 / x; }
+inline void fast_sqrt_rsqrt(double x, double& s, double& rs) { s = std::sqrt(x); rs = 1.0 / s; }
 #endif
 
 // One group of G lanes = one problem; "q" = lane within the group; rows q, q + G, ... of W and Y.
 // rec = eigen record of the problem (all lanes of the group pass the same).  Host builds run the
 // same arithmetic with G = 1 (tests/emul), there being no lanes to share with.
+// One-sided (Hestenes) Jacobi, cyclic by rows; per rotation one inner product over the group (the
+// squared column norms are carried along: a' = a - t g, b' = b + t g, and recomputed at the start of
+// every sweep), the angle from fast reciprocals, the update of the own rows of W and Y.
 template <int N, int G>
 SS_HD void coop_eig_unit(double* rec, long stride, int q) {
   constexpr int NR = (N + G - 1) / G;
   using Rec = EigRec<N>;
   if (!(rec_elem_load(rec, stride, Rec::STATUS) > 0.5)) return;   // same for the whole group
-  double w[NR][N], x[NR][N], ax[NR][N];
+  double w[NR][N], y[NR][N], nrm[N];
   SS_UNROLL_FULL
   for (int r = 0; r < NR; ++r) {
     const int i = q + r * G;
     SS_UNROLL_FULL
     for (int j = 0; j < N; ++j) {
       w[r][j] = (i < N) ? rec_elem_load(rec, stride, Rec::W + i * N + j) : 0.0;
-      x[r][j] = (i < N) ? rec_elem_load(rec, stride, Rec::X + i * N + j) : 0.0;
-      ax[r][j] = (i < N) ? rec_elem_load(rec, stride, Rec::AX + i * N + j) : 0.0;
+      y[r][j] = (i == j) ? 1.0 : 0.0;
     }
   }
   auto gsum = [](double v) {
@@ -236,47 +299,54 @@ SS_HD void coop_eig_unit(double* rec, long stride, int q) {
     return v;
 #endif
   };
-  // cyclic sweeps; a sweep without a rotation ends the iteration (the decision is taken on
-  // group-wide sums, so the lanes of a group agree on it)
+  // a sweep without a rotation ends the iteration (the decision is taken on group-wide sums, so
+  // the lanes of a group agree on it)
   constexpr double tol = 4.0 * DBL_EPSILON;
   for (int sweep = 0; sweep < 30; ++sweep) {
+    SS_UNROLL_FULL
+    for (int j = 0; j < N; ++j) {
+      double s = 0.0;
+      SS_UNROLL_FULL
+      for (int r = 0; r < NR; ++r) s += w[r][j] * w[r][j];
+      nrm[j] = gsum(s);
+    }
     bool rotated = false;
     SS_UNROLL_FULL
     for (int p = 0; p < N - 1; ++p) {
       SS_UNROLL_FULL
       for (int c = p + 1; c < N; ++c) {
-        double app = 0.0, acc = 0.0, apc = 0.0;
+        double apc = 0.0;
         SS_UNROLL_FULL
-        for (int r = 0; r < NR; ++r) {
-          app += w[r][p] * w[r][p];
-          acc += w[r][c] * w[r][c];
-          apc += w[r][p] * w[r][c];
-        }
-        app = gsum(app);
-        acc = gsum(acc);
+        for (int r = 0; r < NR; ++r) apc += w[r][p] * w[r][c];
         apc = gsum(apc);
+        const double app = nrm[p], acc = nrm[c];
         if (apc * apc > (tol * tol) * (app * acc)) {
           rotated = true;
-          // Rutishauser's formulas: the smaller rotation angle
-          const double zeta = (acc - app) / (2.0 * apc);
-          const double t = ss_sign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-          const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+          // the smaller rotation angle (Rutishauser): t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)),
+          // zeta = (acc - app) / (2 apc), written without the division by apc
+          const double d = acc - app, g2 = apc + apc;
+          double sq, rsq_unused;
+          fast_sqrt_rsqrt(d * d + g2 * g2, sq, rsq_unused);
+          const double t = ((d >= 0.0) ? g2 : -g2) * fast_rcp(fabs(d) + sq);
+          double cs_inv, cs;
+          fast_sqrt_rsqrt(1.0 + t * t, cs_inv, cs);
+          const double sn = cs * t;
+          nrm[p] = app - t * apc;
+          nrm[c] = acc + t * apc;
           SS_UNROLL_FULL
           for (int r = 0; r < NR; ++r) {
-            const double wp = w[r][p], wc = w[r][c], xp = x[r][p], xc = x[r][c], ap = ax[r][p], ac = ax[r][c];
+            const double wp = w[r][p], wc = w[r][c], yp = y[r][p], yc = y[r][c];
             w[r][p] = cs * wp - sn * wc;
             w[r][c] = sn * wp + cs * wc;
-            x[r][p] = cs * xp - sn * xc;
-            x[r][c] = sn * xp + cs * xc;
-            ax[r][p] = cs * ap - sn * ac;
-            ax[r][c] = sn * ap + cs * ac;
+            y[r][p] = cs * yp - sn * yc;
+            y[r][c] = sn * yp + cs * yc;
           }
         }
       }
     }
     if (!rotated) break;
   }
-  // squared singular values; X and (G1 - G2)^-1 X in place of D L and -D L^-T
+  // squared singular values; Y in place of W
   SS_UNROLL_FULL
   for (int j = 0; j < N; ++j) {
     double s = 0.0;
@@ -290,10 +360,7 @@ SS_HD void coop_eig_unit(double* rec, long stride, int q) {
     const int i = q + r * G;
     if (i < N) {
       SS_UNROLL_FULL
-      for (int j = 0; j < N; ++j) {
-        rec_elem_store(rec, stride, Rec::X + i * N + j, x[r][j]);
-        rec_elem_store(rec, stride, Rec::AX + i * N + j, ax[r][j]);
-      }
+      for (int j = 0; j < N; ++j) rec_elem_store(rec, stride, Rec::W + i * N + j, y[r][j]);
     }
   }
 }

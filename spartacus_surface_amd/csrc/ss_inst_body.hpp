@@ -8,6 +8,7 @@
 #include "ss_solver_sw.hpp"
 #include "ss_layer16.hpp"
 #include "ss_column16.hpp"
+#include "ss_down16.hpp"
 
 namespace ss {
 namespace {
@@ -46,6 +47,9 @@ __global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_LAYER)) k
 #endif
   const int cu = tile * kBlock + threadIdx.x;
   if (cu >= L.ncu) return;
+  if constexpr (STAGE == 2 && r16_layer(R * NS, LW)) {
+    if (L.eigen_fail && L.eigen_fail[kSlotOneLaneUnits] == 0ULL) return;   // every unit went the cooperative way
+  }
   if (LW) layer_unit_lw<U, R, NS, STAGE>(L, cu, jlay);
   else layer_unit_sw<U, R, NS, STAGE>(L, cu, jlay);
 }
@@ -54,7 +58,7 @@ __global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_LAYER)) k
 // block -> (tile of 64 units, layer, quarter of the tile); 4 lanes per unit, 16 units per wave
 template <int N>
 __global__ void __launch_bounds__(kBlock, 1) k_eig_coop(const Launch L) {
-  constexpr int G = kCoopLanes;
+  constexpr int G = coop_lanes(N);
   const int part = blockIdx.x % G, tl = blockIdx.x / G;
   const int tile = tl / L.maxlay, jlay = tl % L.maxlay;
   const int cu = tile * kBlock + part * (kBlock / G) + (int)threadIdx.x / G;
@@ -72,6 +76,23 @@ __global__ void __launch_bounds__(kBlock, 1) k_layer_up(const Launch L) {
   if constexpr (fused_order(R * NS, LW)) {
     if constexpr (LW) layer_up_lw<U, R, NS>(L, cu);
     else layer_up_sw<U, R, NS>(L, cu);
+  }
+}
+
+// Cholesky factors of the cooperative units (W, D L, -D L^-T of the eigen record) on the 16 lanes of a
+// DPP row, between the first pass of the layer kernel and the Jacobi kernel; block -> units as k_layer16
+template <int N>
+__global__ void __launch_bounds__(kBlock, 2) k_pre16(const Launch L) {
+  constexpr int UPB = kBlock / r16::kRow;
+  const int part = blockIdx.x % r16::kRow, tl = blockIdx.x / r16::kRow;
+  const int tile = tl / L.maxlay, jlay = tl % L.maxlay;
+  const int cu = tile * kBlock + part * UPB + (int)threadIdx.x / r16::kRow;
+  if (cu >= L.ncu) return;
+  if (jlay >= L.in.nlay[L.cols[cu / L.nspec]]) return;
+  if constexpr (coop_order(N)) {
+    double* erec = L.eig + rec_base(jlay, L.maxlay, EigRec<N>::NELEM, cu);
+    if (!(rec_elem_load(erec, kRecStride, EigRec<N>::STATUS) > 0.5)) return;     // same for the whole row
+    r16::eig_pre<N>(erec, kRecStride, L.eigen_fail ? L.eigen_fail + kSlotOneLaneUnits : nullptr);
   }
 }
 
@@ -113,6 +134,17 @@ __global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_COLUMN)) 
   if (cu >= L.ncu) return;
   if (LW) column_up_lw<U, R, NS>(L, cu);
   else column_up_sw<U, R, NS>(L, cu);
+}
+
+// downward passes of the cooperative orders: one column unit (both passes) on the 16 lanes of a DPP row
+template <bool U, int R, int NS, bool LW>
+__global__ void __launch_bounds__(kBlock, 2) k_down16(const Launch L) {
+  const int cu = blockIdx.x * (kBlock / r16::kRow) + (int)threadIdx.x / r16::kRow;
+  if (cu >= L.ncu) return;
+  if constexpr (r16_layer(R * NS, LW)) {
+    if constexpr (LW) r16::column_down_lw<U, R, NS>(L, cu);
+    else r16::column_down_sw<U, R, NS>(L, cu);
+  }
 }
 
 // downward flux sweep: vectors only, several waves per SIMD
@@ -164,7 +196,11 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev) {
     hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0, 1>), glayer, dim3(kBlock), 0,
                        stream, L);
     SS_TRY(hipGetLastError());
-    hipLaunchKernelGGL((k_eig_coop<SS_INST_NREG * NS>), dim3(gx * (unsigned)L.maxlay * kCoopLanes), dim3(kBlock), 0, stream, L);
+    if constexpr (r16_layer(SS_INST_NREG * NS, SS_INST_LW != 0)) {
+      hipLaunchKernelGGL((k_pre16<SS_INST_NREG * NS>), dim3(gx * (unsigned)L.maxlay * r16::kRow), dim3(kBlock), 0, stream, L);
+      SS_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL((k_eig_coop<SS_INST_NREG * NS>), dim3(gx * (unsigned)L.maxlay * coop_lanes(SS_INST_NREG * NS)), dim3(kBlock), 0, stream, L);
     SS_TRY(hipGetLastError());
     if constexpr (r16_layer(SS_INST_NREG * NS, SS_INST_LW != 0)) {
       hipLaunchKernelGGL((k_layer16<SS_INST_NREG * NS, SS_INST_NREG, SS_INST_LW != 0>), dim3(gx * (unsigned)L.maxlay * r16::kRow),
@@ -190,7 +226,12 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev) {
   }
   SS_TRY(hipGetLastError());
   if (ev) SS_TRY(hipEventRecord(ev[2], stream));
-  {
+  if constexpr (r16_layer(SS_INST_NREG * NS, SS_INST_LW != 0)) {
+    constexpr unsigned upb = kBlock / r16::kRow;
+    hipLaunchKernelGGL((k_down16<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>),
+                       dim3(((unsigned)L.ncu + upb - 1) / upb), dim3(kBlock), 0, stream, L);
+    SS_TRY(hipGetLastError());
+  } else {
     const unsigned gd = (unsigned)((2L * L.ncu + kBlock - 1) / kBlock);
     hipLaunchKernelGGL((k_down<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gd), dim3(kBlock), 0,
                        stream, L);

@@ -45,6 +45,116 @@ SS_HD void store_vec(double* rec, long stride, int off, const rv& x) {
   each(x, [&](int i, double v) { if (i < N) rec_elem_store(rec, stride, off + i, v); });
 }
 
+// Symmetric elimination of an s.p.d. matrix with its rows on the lanes (both triangles are kept up
+// to date, so that the multiplier of row i in step j is its own element j): on return Lr = own row of
+// the Cholesky factor L (A = L L^T), A = own row of L^T scaled by the own pivot root (row i of L^T is
+// A[k] * rs_own for k >= i), rs[j] = 1 / sqrt(pivot j) on every lane.  Returns false when a pivot is
+// not above "thr" (the lanes of a row agree).
+template <int N>
+SS_HD bool cholesky_rows(rv* A, rv* Lr, double* rs, double thr) {
+  bool ok = true;
+  static_for<0, N>([&](auto jc) {
+    constexpr int J = decltype(jc)::value;
+    const double piv = bc<J>(A[J]);
+    if (!(piv > thr)) ok = false;
+    const double r = 1.0 / sqrt(ok ? piv : 1.0);
+    rs[J] = r;
+    const rv l = A[J] * r;
+    Lr[J] = select(lane_lt(J), rv(0.0), l);
+    row_fma_from<J, J + 1, N>(A, A, select(lane_gt(J), -(l * r), rv(0.0)));
+  });
+  return ok;
+}
+
+// The factors the cooperative Jacobi kernel and the layer kernel need (what coop_eig_pre does on one
+// lane): with C = -D^-1 (G1 - G2) D = L L^T and M = C - 2 D^-1 G2 D = F F^T: W = F^T L, D L, -D L^-T.
+// In: G1, G2, dscale and the size of the scaled matrices (EV slot 0) as the first pass of the layer
+// kernel left them.  A unit whose matrices are not positive definite gets status 0 (second pass, general solver).
+template <int N>
+SS_HD void eig_pre(double* erec, long stride, unsigned long long* one_lane_units) {
+  using ER = EigRec<N>;
+  const double size = rec_elem_load(erec, stride, ER::EV);
+  const rv dsc = load_vec<N>(erec, stride, ER::VEC);
+  double d[N];
+  all_of<N>(dsc, d);
+  const rv rd = select(lane_lt(N), 1.0 / (dsc + select(lane_lt(N), rv(0.0), rv(1.0))), rv(0.0));
+  rv C[N], M[N];
+  {
+    rv g1[N], g2[N];
+    load_rowmajor<N, N>(erec, stride, ER::G1, g1);
+    load_rowmajor<N, N>(erec, stride, ER::G2, g2);
+    SS_UNROLL_FULL
+    for (int j = 0; j < N; ++j) {
+      const rv sc = rd * d[j];
+      C[j] = -((g1[j] - g2[j]) * sc);
+      M[j] = C[j] - 2.0 * (g2[j] * sc);
+    }
+    // rows beyond the order: identity (their pivots are never used, but keep the arithmetic finite)
+    SS_UNROLL_FULL
+    for (int j = 0; j < N; ++j) {
+      C[j] = select(lane_lt(N), C[j], rv(0.0));
+      M[j] = select(lane_lt(N), M[j], rv(0.0));
+    }
+  }
+  rv L[N], F[N];
+  double rsL[N], rsF[N];
+  bool ok = cholesky_rows<N>(C, L, rsL, 1.0e-14 * size);
+  ok = cholesky_rows<N>(M, F, rsF, 1.0e-14 * size) && ok;
+  if (!ok) {
+    if (lane0()) {
+      rec_elem_store(erec, stride, ER::STATUS, 0.0);
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (one_lane_units) atomicAdd(one_lane_units, 1ULL);
+#else
+      if (one_lane_units) *one_lane_units += 1ULL;
+#endif
+    }
+    return;
+  }
+  // own rows of F^T (M holds them scaled by the own pivot root) and of L^T
+  const rv rsF_own = own<N>(rsF), rsL_own = own<N>(rsL);
+  {
+    rv FT[N], W[N];
+    SS_UNROLL_FULL
+    for (int k = 0; k < N; ++k) FT[k] = select(lane_gt(k), rv(0.0), M[k] * rsF_own);
+    mul<N, N, false, false>(FT, nullptr, L, W);
+    SS_UNROLL_FULL
+    for (int j = 0; j < N; ++j)
+      each(W[j], [&](int i, double x) { if (i < N) rec_elem_store(erec, stride, ER::W + i * N + j, x); });
+  }
+  SS_UNROLL_FULL
+  for (int j = 0; j < N; ++j)
+    each(L[j] * dsc, [&](int i, double x) { if (i < N) rec_elem_store(erec, stride, ER::X + i * N + j, x); });
+  // -D L^-T: R = L^T is upper triangular with its rows on the lanes; R X = I by back substitution
+  {
+    rv X[N];
+    SS_UNROLL_FULL
+    for (int j = 0; j < N; ++j) X[j] = select(lane_eq(j), rv(1.0), rv(0.0));
+    static_for_down<1, N>([&](auto kc) {
+      constexpr int K = decltype(kc)::value;
+      // R(i, K) = C[K] * rsL_own for i <= K; x_K = (row K of X) / R(K, K) = (row K) * rsL[K]
+      const rv u = select(lane_lt(K), (C[K] * rsL_own) * rsL[K], rv(0.0));
+      row_fma<K, N>(X, X, -u);
+    });
+    const rv sc = -(dsc * rsL_own);
+    SS_UNROLL_FULL
+    for (int j = 0; j < N; ++j)
+      each(X[j] * sc, [&](int i, double x) { if (i < N) rec_elem_store(erec, stride, ER::AX + i * N + j, x); });
+  }
+}
+
+// Eigenvectors X = (D L) Y and (G1 - G2)^-1 X = (-D L^-T) Y from the factors and the rotations of the record
+template <int N>
+SS_HD void load_eigenvectors(const double* erec, long stride, rv* X, rv* AX) {
+  using ER = EigRec<N>;
+  rv Y[N], F[N];
+  load_rowmajor<N, N>(erec, stride, ER::W, Y);
+  load_rowmajor<N, N>(erec, stride, ER::X, F);
+  mul<N, N, false, false>(F, nullptr, Y, X);
+  load_rowmajor<N, N>(erec, stride, ER::AX, F);
+  mul<N, N, false, false>(F, nullptr, Y, AX);
+}
+
 // Diffuse part (sw_eig :180-221, lw_eig :142-176): from eigenvalues, X and (G1 - G2)^-1 X of the
 // record to the eigenvector blocks G1, G2, lam, e = exp(-lam dz), LU(G1), C'_lower, C'_upper; R and T
 // go to the layer record (column-major blocks at offR, offT).
@@ -52,32 +162,45 @@ template <int N>
 struct Diffuse {
   rv G1[N], G2[N], Clo[N], Cup[N];
   LU<N> luG1;
-  double lam[N], e[N];
   rv lam_d, e_d;
 };
+
+// B = diag(e) A (e one element per lane: the own row scaled)
+template <int M>
+SS_HD void scale_rows(const rv* A, const rv& e_d, rv* B) {
+  SS_UNROLL_FULL
+  for (int j = 0; j < M; ++j) B[j] = A[j] * e_d;
+}
 
 template <int N>
 SS_HD void diffuse_part(const rv* X, const rv* AX, const rv& ev_d, double dz, Diffuse<N>& w, double* lrec,
                         long stride, int offR, int offT) {
   w.lam_d = r_sqrt(r_max(ev_d, 0.0));
   w.e_d = r_exp(-(w.lam_d * dz));
-  all_of<N>(w.lam_d, w.lam);
-  all_of<N>(w.e_d, w.e);
   rv t1[N];
-  // tmp = -((G1 - G2)^-1 X) diag(lam);  G1 = X + tmp, G2 = X - tmp
-  SS_UNROLL_FULL
-  for (int j = 0; j < N; ++j) {
-    const rv t = -(AX[j] * w.lam[j]);
-    w.G1[j] = X[j] + t;
-    w.G2[j] = X[j] - t;
-    w.luG1.a[j] = w.G1[j];
-    t1[j] = w.G2[j];
+  {
+    // tmp = -((G1 - G2)^-1 X) diag(lam);  G1 = X + tmp, G2 = X - tmp
+    double lam[N];
+    all_of<N>(w.lam_d, lam);
+    SS_UNROLL_FULL
+    for (int j = 0; j < N; ++j) {
+      const rv t = -(AX[j] * lam[j]);
+      w.G1[j] = X[j] + t;
+      w.G2[j] = X[j] - t;
+      w.luG1.a[j] = w.G1[j];
+      t1[j] = w.G2[j];
+    }
   }
-  // Eq. 48 by Schur complement; G1D = G1 diag(e), G2D = G2 diag(e) are never formed
+  // Eq. 48 by Schur complement; G1D = G1 diag(e), G2D = G2 diag(e) are never formed: the scaling
+  // goes to the rows of the right-hand factor (one multiplication by the own element of e)
   lu_factor<N>(w.luG1);
   lu_solve<N, N>(w.luG1, t1);                               // G1^-1 G2
-  SS_UNROLL_FULL
-  for (int j = 0; j < N; ++j) t1[j] = t1[j] * (w.e_d * w.e[j]);   // diag(e) G1^-1 G2 diag(e)
+  {
+    double e[N];
+    all_of<N>(w.e_d, e);
+    SS_UNROLL_FULL
+    for (int j = 0; j < N; ++j) t1[j] = t1[j] * (w.e_d * e[j]);   // diag(e) G1^-1 G2 diag(e)
+  }
   {
     LU<N> S;
     mul<N, N, false, false>(w.G2, nullptr, t1, S.a);        // G2D G1^-1 G2D
@@ -89,17 +212,22 @@ SS_HD void diffuse_part(const rv* X, const rv* AX, const rv& ev_d, double dz, Di
     lu_factor<N>(S);
     lu_solve<N, N>(S, w.Clo);                               // C'_lower = S^-1
   }
-  mul<N, N, false, true>(w.G2, w.e, w.Clo, w.Cup);          // G2D Clo
+  scale_rows<N>(w.Clo, w.e_d, t1);
+  mul<N, N, false, false>(w.G2, nullptr, t1, w.Cup);        // G2D Clo
   lu_solve<N, N>(w.luG1, w.Cup);
   SS_UNROLL_FULL
   for (int j = 0; j < N; ++j) w.Cup[j] = -w.Cup[j];         // C'_upper
   // Eq. 49: R = G1D Cup + G2 Clo ; T = G2 Cup + G1D Clo
-  mul<N, N, false, false>(w.G2, nullptr, w.Clo, t1);
-  mul<N, N, true, true>(w.G1, w.e, w.Cup, t1);
-  store_colmajor<N, N>(lrec, stride, offR, t1);
-  mul<N, N, false, false>(w.G2, nullptr, w.Cup, t1);
-  mul<N, N, true, true>(w.G1, w.e, w.Clo, t1);
-  store_colmajor<N, N>(lrec, stride, offT, t1);
+  {
+    rv acc[N];
+    mul<N, N, false, false>(w.G1, nullptr, t1, acc);        // G1D Clo (t1 = diag(e) Clo)
+    mul<N, N, true, false>(w.G2, nullptr, w.Cup, acc);
+    store_colmajor<N, N>(lrec, stride, offT, acc);
+    scale_rows<N>(w.Cup, w.e_d, t1);
+    mul<N, N, false, false>(w.G1, nullptr, t1, acc);        // G1D Cup
+    mul<N, N, true, false>(w.G2, nullptr, w.Clo, acc);
+    store_colmajor<N, N>(lrec, stride, offR, acc);
+  }
 }
 
 // calc_matrices_lw_eig of a full problem: layer record of the unit from its eigen record
@@ -125,8 +253,7 @@ SS_HD void layer_lw(const double* erec, long stride, double* lrec) {
   Diffuse<N> df;
   {
     rv X[N], AX[N];
-    load_rowmajor<N, N>(erec, stride, ER::X, X);
-    load_rowmajor<N, N>(erec, stride, ER::AX, AX);
+    load_eigenvectors<N>(erec, stride, X, AX);
     diffuse_part<N>(X, AX, load_vec<N>(erec, stride, ER::EV), dz, df, lrec, stride, LR::R, LR::T);
   }
   // Section 4 (:198-209): cb' and the source
@@ -169,27 +296,20 @@ SS_HD void layer_sw(const double* erec, long stride, double* lrec) {
   using ER = EigRec<N>;
   using LR = SwRec<N, D>;
   const double dz = rec_elem_load(erec, stride, 1);
-  double mu[D], G0[D * D], G0inv[D * D], emu[D];
-  SS_UNROLL_FULL
-  for (int r = 0; r < D; ++r) {
-    mu[r] = rec_elem_load(erec, stride, ER::vmu(D) + r);
-    emu[r] = rec_elem_load(erec, stride, ER::vemu(D) + r);
-  }
-  SS_UNROLL_FULL
-  for (int k = 0; k < D * D; ++k) {
-    G0[k] = rec_elem_load(erec, stride, ER::vg0(D) + k);
-    G0inv[k] = rec_elem_load(erec, stride, ER::vg0inv(D) + k);
-  }
   const rv ev_d = load_vec<N>(erec, stride, ER::EV);
   rv g3v[D], g4v[D];   // particular solutions, one column per direct eigenvalue
   Diffuse<N> df;
   {
     rv X[N], AX[N];
-    load_rowmajor<N, N>(erec, stride, ER::X, X);
-    load_rowmajor<N, N>(erec, stride, ER::AX, AX);
+    load_eigenvectors<N>(erec, stride, X, AX);
     // Section 4 (:231-253) through the eigen-decomposition (see ss_layer_matrices.hpp): sources
     // s = g3 G0 (one column per direct eigenvalue), c = 2 (Lambda - mu^2)^-1 (D^-2 X)^T s,
     // p = X c, q = -mu ((G1 - G2)^-1 X) c, g3 = (p + q) / 2, g4 = (p - q) / 2
+    double mu[D], G0[D * D];
+    SS_UNROLL_FULL
+    for (int r = 0; r < D; ++r) mu[r] = rec_elem_load(erec, stride, ER::vmu(D) + r);
+    SS_UNROLL_FULL
+    for (int k = 0; k < D * D; ++k) G0[k] = rec_elem_load(erec, stride, ER::vg0(D) + k);
     rv g3[D];
     load_rowmajor<N, D>(erec, stride, ER::vg3(), g3);
     const rv dsc = load_vec<N>(erec, stride, ER::VEC);
@@ -223,11 +343,22 @@ SS_HD void layer_sw(const double* erec, long stride, double* lrec) {
       g3v[jd] = 0.5 * (pv + q);
       g4v[jd] = 0.5 * (pv - q);
     }
+    // (the particular solutions wait in the S_up / S_dn slots of the record while the diffuse part
+    // needs the registers)
+    store_colmajor<N, D>(lrec, stride, LR::SUP, g3v);
+    store_colmajor<N, D>(lrec, stride, LR::SDN, g4v);
     // Sections 1-2: diffuse R, T
     diffuse_part<N>(X, AX, ev_d, dz, df, lrec, stride, LR::R, LR::T);
   }
+  load_colmajor<N, D>(lrec, stride, LR::SUP, g3v);
+  load_colmajor<N, D>(lrec, stride, LR::SDN, g4v);
   // direct_diffuse_part (:303-386) by block elimination (header of ss_layer_matrices.hpp)
   {
+    double G0inv[D * D], emu[D];
+    SS_UNROLL_FULL
+    for (int r = 0; r < D; ++r) emu[r] = rec_elem_load(erec, stride, ER::vemu(D) + r);
+    SS_UNROLL_FULL
+    for (int k = 0; k < D * D; ++k) G0inv[k] = rec_elem_load(erec, stride, ER::vg0inv(D) + k);
     rv b1[D], b2[D], c1[D], c2[D], t[D], te[D], su[D];
     SS_UNROLL_FULL
     for (int j = 0; j < D; ++j) {

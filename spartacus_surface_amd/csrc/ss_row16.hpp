@@ -20,6 +20,9 @@
 // inline asm, so every asm block opens with s_nop 1; the blocks are volatile: they keep their
 // program order and are never sunk into divergent control flow (a DPP read of a lane that EXEC
 // has switched off does not happen: all 16 lanes of a row always take the same branches).
+// They also clobber "memory": loads and stores stay where they are written relative to the
+// arithmetic (the scheduler otherwise hoists every load of a kernel to its top, and the matrices
+// they fetch then sit in registers - or in spill slots - until their turn comes).
 //
 // Host builds (tests/emul, TEST-ONLY) run the same code on a pack of 16 doubles.
 #pragma once
@@ -83,28 +86,28 @@ SS_HD double bc(rv x) {
 #define SS_R16_L(o, i) "v_fmac_f64_dpp %" #o ", %" #i ", %[a] row_newbcast:%[k]" SS_R16_DPP
 template <int K>
 SS_HD void fma1(rv& c0, rv b0, rv a) {
-  asm volatile("s_nop 1\n" SS_R16_L(0, 1) : "+v"(c0) : "v"(b0), [a] "v"(a), [k] "n"(K));
+  asm volatile("s_nop 1\n" SS_R16_L(0, 1) : "+v"(c0) : "v"(b0), [a] "v"(a), [k] "n"(K) : "memory");
 }
 template <int K>
 SS_HD void fma2(rv& c0, rv& c1, rv b0, rv b1, rv a) {
-  asm volatile("s_nop 1\n" SS_R16_L(0, 2) SS_R16_L(1, 3) : "+v"(c0), "+v"(c1) : "v"(b0), "v"(b1), [a] "v"(a), [k] "n"(K));
+  asm volatile("s_nop 1\n" SS_R16_L(0, 2) SS_R16_L(1, 3) : "+v"(c0), "+v"(c1) : "v"(b0), "v"(b1), [a] "v"(a), [k] "n"(K) : "memory");
 }
 template <int K>
 SS_HD void fma3(rv* c, const rv* b, rv a) {
   asm volatile("s_nop 1\n" SS_R16_L(0, 3) SS_R16_L(1, 4) SS_R16_L(2, 5)
-               : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]) : "v"(b[0]), "v"(b[1]), "v"(b[2]), [a] "v"(a), [k] "n"(K));
+               : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]) : "v"(b[0]), "v"(b[1]), "v"(b[2]), [a] "v"(a), [k] "n"(K) : "memory");
 }
 template <int K>
 SS_HD void fma4(rv* c, const rv* b, rv a) {
   asm volatile("s_nop 1\n" SS_R16_L(0, 4) SS_R16_L(1, 5) SS_R16_L(2, 6) SS_R16_L(3, 7)
                : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
-               : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), [a] "v"(a), [k] "n"(K));
+               : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), [a] "v"(a), [k] "n"(K) : "memory");
 }
 template <int K>
 SS_HD void fma6(rv* c, const rv* b, rv a) {
   asm volatile("s_nop 1\n" SS_R16_L(0, 6) SS_R16_L(1, 7) SS_R16_L(2, 8) SS_R16_L(3, 9) SS_R16_L(4, 10) SS_R16_L(5, 11)
                : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5])
-               : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), [a] "v"(a), [k] "n"(K));
+               : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), [a] "v"(a), [k] "n"(K) : "memory");
 }
 template <int K>
 SS_HD void fma12(rv* c, const rv* b, rv a) {
@@ -114,7 +117,7 @@ SS_HD void fma12(rv* c, const rv* b, rv a) {
                : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]),
                  "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11])
                : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8]),
-                 "v"(b[9]), "v"(b[10]), "v"(b[11]), [a] "v"(a), [k] "n"(K));
+                 "v"(b[9]), "v"(b[10]), "v"(b[11]), [a] "v"(a), [k] "n"(K) : "memory");
 }
 #undef SS_R16_L
 // c[j] += bcast_K(b[j]) * a for j = J0 .. M-1, in as few asm blocks as the operand limit allows
@@ -242,12 +245,12 @@ SS_HD void mat_vec(const rv* A, const rv& x, rv& y) {
   y = y0 + y1;
 }
 
-// unpivoted LU in place (unit lower factor below the diagonal), reciprocal pivots on every lane
-// (rd) and the own one (rdd)
+// unpivoted LU in place: below the diagonal the unit lower factor, above it U with column k scaled
+// by 1 / u_kk (the form the upward substitution wants), on the diagonal the pivots; rdd = reciprocal
+// of the own pivot
 template <int N>
 struct LU {
   rv a[N];
-  double rd[N];
   rv rdd;
 };
 template <int N>
@@ -256,26 +259,24 @@ SS_HD void lu_factor(LU<N>& f) {
   static_for<0, N>([&](auto kc) {
     constexpr int K = decltype(kc)::value;
     const double rp = 1.0 / bc<K>(f.a[K]);
-    f.rd[K] = rp;
     f.rdd = select(lane_eq(K), rv(rp), f.rdd);
-    const rv l = select(lane_gt(K), f.a[K] * rp, rv(0.0));
-    f.a[K] = select(lane_gt(K), l, f.a[K]);
+    const rv s = f.a[K] * rp;                       // rows above: u_ik / u_kk (final), rows below: l_ik
+    const rv l = select(lane_gt(K), s, rv(0.0));
+    f.a[K] = select(lane_eq(K), f.a[K], s);
     row_fma_from<K, K + 1, N>(f.a, f.a, -l);
   });
 }
-// X <- (L U)^-1 X, X with M columns.  Upward: row k is used unscaled, x_k = rd_k * (row k), so the
-// update of row i < k is  -(u_ik rd_k) * (row k), and every row is scaled by its own pivot at the end.
+// X <- (L U)^-1 X, X with M columns.  Upward: row k is used unscaled, x_k = (row k) / u_kk, so the
+// update of row i < k is  -(u_ik / u_kk) * (row k), and every row is scaled by its own pivot at the end.
 template <int N, int M>
 SS_HD void lu_solve(const LU<N>& f, rv* X) {
   static_for<0, N - 1>([&](auto kc) {
     constexpr int K = decltype(kc)::value;
-    const rv l = select(lane_gt(K), f.a[K], rv(0.0));
-    row_fma<K, M>(X, X, -l);
+    row_fma<K, M>(X, X, select(lane_gt(K), -f.a[K], rv(0.0)));
   });
   static_for_down<1, N>([&](auto kc) {
     constexpr int K = decltype(kc)::value;
-    const rv u = select(lane_lt(K), f.a[K] * f.rd[K], rv(0.0));
-    row_fma<K, M>(X, X, -u);
+    row_fma<K, M>(X, X, select(lane_lt(K), -f.a[K], rv(0.0)));
   });
   SS_UNROLL_FULL
   for (int j = 0; j < M; ++j) X[j] = X[j] * f.rdd;

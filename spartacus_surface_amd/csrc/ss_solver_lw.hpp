@@ -210,22 +210,37 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
     const bool full = !(NREG == 1 || p.g.veg_fraction <= L.cfg.min_vegetation_fraction)
                       && !(p.frac[0] <= L.cfg.min_vegetation_fraction);
     if (full) {
-      double GD[N * N];
-      for (int k = 0; k < N * N; ++k) GD[k] = g1[k] - g2[k];
-      if (coop_eig_pre<N>(GD, g2, dsc, erec, kRecStride) && r16_layer(N, true)) {
-        // what the layer kernel of the row-of-16 layout (ss_layer16.hpp) needs of this unit, row-major
-        rec_elem_store(erec, kRecStride, 1, p.g.dz);
-        for (int i = 0; i < N; ++i) {
-          for (int j = 0; j < N; ++j) {
-            rec_elem_store(erec, kRecStride, EigRec<N>::G1 + i * N + j, SS_E(g1, i, j, N));
-            rec_elem_store(erec, kRecStride, EigRec<N>::G2 + i * N + j, SS_E(g2, i, j, N));
+      if constexpr (r16_layer(N, true)) {
+        // what the row-of-16 kernels (ss_layer16.hpp: eig_pre, layer_lw) need of this unit, matrices row-major
+        double size;
+        const bool ok = coop_eig_check<N>(g1, g2, dsc, size);
+        rec_elem_store(erec, kRecStride, EigRec<N>::STATUS, ok ? 1.0 : 0.0);
+        if (ok) {
+          rec_elem_store(erec, kRecStride, 1, p.g.dz);
+          rec_elem_store(erec, kRecStride, EigRec<N>::EV, size);
+          for (int i = 0; i < N; ++i) {
+            for (int j = 0; j < N; ++j) {
+              rec_elem_store(erec, kRecStride, EigRec<N>::G1 + i * N + j, SS_E(g1, i, j, N));
+              rec_elem_store(erec, kRecStride, EigRec<N>::G2 + i * N + j, SS_E(g2, i, j, N));
+            }
+            rec_elem_store(erec, kRecStride, EigRec<N>::VEC + i, dsc[i]);
+            rec_elem_store(erec, kRecStride, EigRec<N>::VEC + N + i, b[i]);
           }
-          rec_elem_store(erec, kRecStride, EigRec<N>::VEC + i, dsc[i]);
-          rec_elem_store(erec, kRecStride, EigRec<N>::VEC + N + i, b[i]);
         }
+      } else {
+        double GD[N * N];
+        for (int k = 0; k < N * N; ++k) GD[k] = g1[k] - g2[k];
+        coop_eig_pre<N>(GD, g2, dsc, erec, kRecStride);
       }
     } else {
       rec_elem_store(erec, kRecStride, EigRec<N>::STATUS, 0.0);
+    }
+    if (L.eigen_fail && !(rec_elem_load(erec, kRecStride, EigRec<N>::STATUS) > 0.5)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      atomicAdd(L.eigen_fail + kSlotOneLaneUnits, 1ULL);
+#else
+      L.eigen_fail[kSlotOneLaneUnits] += 1ULL;
+#endif
     }
     return;
   }

@@ -195,36 +195,55 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
     const bool full = !(NREG == 1 || g.veg_fraction <= L.cfg.min_vegetation_fraction)
                       && !(frac[0] <= L.cfg.min_vegetation_fraction);
     if (full) {
-      double GD[N * N];
-      for (int k = 0; k < N * N; ++k) GD[k] = g1[k] - g2[k];
-      if (coop_eig_pre<N>(GD, g2, dsc, erec, kRecStride) && r16_layer(N, false)) {
-        // The direct-beam part of the unit (D x D: one lane does it for its unit here, the 16 lanes
-        // of the row-of-16 kernel would each repeat it): int_dir and E go to the layer record, the
-        // eigen-decomposition of Gamma0 and what else ss_layer16.hpp needs to the eigen record
-        using ER = EigRec<N>;
-        double mu[D], G0[D * D], G0inv[D * D], emu[D];
-        const int rc = sw_direct_part<N, D>(g0, dsc0, g.dz, w, mu, G0, G0inv, emu);
+      if constexpr (r16_layer(N, false)) {
+        double size;
+        const bool ok = coop_eig_check<N>(g1, g2, dsc, size);
+        rec_elem_store(erec, kRecStride, EigRec<N>::STATUS, ok ? 1.0 : 0.0);
+        if (ok) {
+          // The direct-beam part of the unit (D x D: one lane does it for its unit here, the 16 lanes
+          // of the row-of-16 kernel would each repeat it): int_dir and E go to the layer record, the
+          // eigen-decomposition of Gamma0 and what else ss_layer16.hpp needs to the eigen record
+          using ER = EigRec<N>;
+          double mu[D], G0[D * D], G0inv[D * D], emu[D];
+          const int rc = sw_direct_part<N, D>(g0, dsc0, g.dz, w, mu, G0, G0inv, emu);
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (rc != 0 && L.eigen_fail) atomicAdd(L.eigen_fail, 1ULL);
+          if (rc != 0 && L.eigen_fail) atomicAdd(L.eigen_fail, 1ULL);
 #else
-        if (rc != 0 && L.eigen_fail) *L.eigen_fail += 1ULL;
+          if (rc != 0 && L.eigen_fail) *L.eigen_fail += 1ULL;
 #endif
-        rec_elem_store(erec, kRecStride, 1, g.dz);
-        for (int i = 0; i < N; ++i) {
-          rec_elem_store(erec, kRecStride, ER::VEC + i, dsc[i]);
-          for (int r = 0; r < D; ++r) rec_elem_store(erec, kRecStride, ER::vg3() + i * D + r, SS_E(g3, i, r, N));
+          rec_elem_store(erec, kRecStride, 1, g.dz);
+          rec_elem_store(erec, kRecStride, ER::EV, size);
+          for (int i = 0; i < N; ++i) {
+            for (int j = 0; j < N; ++j) {
+              rec_elem_store(erec, kRecStride, ER::G1 + i * N + j, SS_E(g1, i, j, N));
+              rec_elem_store(erec, kRecStride, ER::G2 + i * N + j, SS_E(g2, i, j, N));
+            }
+            rec_elem_store(erec, kRecStride, ER::VEC + i, dsc[i]);
+            for (int r = 0; r < D; ++r) rec_elem_store(erec, kRecStride, ER::vg3() + i * D + r, SS_E(g3, i, r, N));
+          }
+          for (int r = 0; r < D; ++r) {
+            rec_elem_store(erec, kRecStride, ER::vmu(D) + r, mu[r]);
+            rec_elem_store(erec, kRecStride, ER::vemu(D) + r, emu[r]);
+          }
+          for (int k = 0; k < D * D; ++k) {
+            rec_elem_store(erec, kRecStride, ER::vg0(D) + k, G0[k]);
+            rec_elem_store(erec, kRecStride, ER::vg0inv(D) + k, G0inv[k]);
+          }
         }
-        for (int r = 0; r < D; ++r) {
-          rec_elem_store(erec, kRecStride, ER::vmu(D) + r, mu[r]);
-          rec_elem_store(erec, kRecStride, ER::vemu(D) + r, emu[r]);
-        }
-        for (int k = 0; k < D * D; ++k) {
-          rec_elem_store(erec, kRecStride, ER::vg0(D) + k, G0[k]);
-          rec_elem_store(erec, kRecStride, ER::vg0inv(D) + k, G0inv[k]);
-        }
+      } else {
+        double GD[N * N];
+        for (int k = 0; k < N * N; ++k) GD[k] = g1[k] - g2[k];
+        coop_eig_pre<N>(GD, g2, dsc, erec, kRecStride);
       }
     } else {
       rec_elem_store(erec, kRecStride, EigRec<N>::STATUS, 0.0);
+    }
+    if (L.eigen_fail && !(rec_elem_load(erec, kRecStride, EigRec<N>::STATUS) > 0.5)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      atomicAdd(L.eigen_fail + kSlotOneLaneUnits, 1ULL);
+#else
+      L.eigen_fail[kSlotOneLaneUnits] += 1ULL;
+#endif
     }
     return;
   }

@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(64) k_unit_coop_pre(const UnitArgs A) {
 }
 template <int N>
 __global__ void __launch_bounds__(64) k_unit_coop_eig(const UnitArgs A) {
-  constexpr int G = ss::kCoopLanes;
+  constexpr int G = ss::coop_lanes(N);
   const int m = blockIdx.x * (64 / G) + (int)threadIdx.x / G;
   if (m >= A.nmat) return;
   if constexpr (ss::coop_order(N))
@@ -217,7 +217,7 @@ int finish(Stage& s, const char* what) {
   if (ss::coop_order(NN) && A.dsc) {                                                                \
     A.eig = static_cast<double*>(s.raw(tiles * 64 * (size_t)ss::EigRec<NN>::NELEM * sizeof(double)));   \
     if (s.err == hipSuccess) hipLaunchKernelGGL((k_unit_coop_pre<NN>), dim3(tiles), dim3(64), 0, 0, A); \
-    if (s.err == hipSuccess) hipLaunchKernelGGL((k_unit_coop_eig<NN>), dim3((nmat + 64 / ss::kCoopLanes - 1) / (64 / ss::kCoopLanes)), dim3(64), 0, 0, A); \
+    if (s.err == hipSuccess) hipLaunchKernelGGL((k_unit_coop_eig<NN>), dim3((nmat + 64 / ss::coop_lanes(NN) - 1) / (64 / ss::coop_lanes(NN))), dim3(64), 0, 0, A); \
   }
 #define UNIT_SW_CASE(NN, DD)                                                                        \
   if (ndiff == NN && ndir == DD) {                                                                  \
