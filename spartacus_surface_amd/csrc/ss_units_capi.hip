@@ -5,8 +5,9 @@
 //   eigen_decomposition_real radtool/radtool_eigen_decomposition.F90:51-828
 // (stacks of nmat independent problems, Fortran layout x(nmat, i, j)).  They launch
 // the SAME __device__ bodies the solver kernels inline (ss_layer_matrices.hpp,
-// ss_eigen*.hpp): one lane per problem, results through the scratch-record writer
-// the layer kernel uses.  A host model that keeps radtool's interface can call
+// ss_eigen*.hpp: one lane per problem; orders 7..16 with a scaling vector: the row-of-16
+// kernels of ss_layer16.hpp around the cooperative Jacobi kernel, as the solver runs them),
+// results through the scratch records the layer kernel writes.  A host model that keeps radtool's interface can call
 // them; the test-suite uses them for known answers on the device (the reference's
 // driver/test_sw.F90 and seeded Gamma sets for every matrix order).
 #include <hip/hip_runtime.h>
@@ -21,6 +22,7 @@
 #include "ss_eigen_coop.hpp"
 #include "ss_layer_matrices.hpp"
 #include "ss_linalg.hpp"
+#include "ss_layer16.hpp"
 
 namespace {
 
@@ -88,8 +90,12 @@ __global__ void __launch_bounds__(64) k_unit_sw(const UnitArgs A) {
   const ss::CoopEig ce{A.eig ? A.eig + ss::rec_base(0, 1, ss::EigRec<N>::NELEM, m) : nullptr, ss::kRecStride};
   if (A.route && ss::coop_order(N) && A.eig)
     A.route[m] = ss::rec_elem_load(ce.rec, ce.stride, ss::EigRec<N>::STATUS) > 0.5 ? 2 : 0;   // 2 = cooperative Jacobi
-  ss::calc_matrices_sw<N, D, N, D, 0, 0>(g0, g1, g2, g3, A.dsc0 ? dsc0 : nullptr, A.dsc ? dsc : nullptr, A.dz, w,
-                                         A.eig ? &ce : nullptr);
+  bool done16 = false;
+  if constexpr (ss::r16_layer(N, false))
+    done16 = A.eig && ss::rec_elem_load(ce.rec, ce.stride, ss::EigRec<N>::STATUS) > 0.5;   // k_unit_layer16 wrote the record
+  if (!done16)
+    ss::calc_matrices_sw<N, D, N, D, 0, 0>(g0, g1, g2, g3, A.dsc0 ? dsc0 : nullptr, A.dsc ? dsc : nullptr, A.dz, w,
+                                           A.eig ? &ce : nullptr);
   __threadfence();
   rec_to_stack<N, N>(rec, Rec::R, A.o0, A.nmat, m);
   rec_to_stack<N, N>(rec, Rec::T, A.o1, A.nmat, m);
@@ -133,7 +139,10 @@ __global__ void __launch_bounds__(64) k_unit_lw(const UnitArgs A) {
   double* rec = A.rec + ss::rec_base(0, 1, Rec::NELEM, m);
   ss::RecWriter w{rec, ss::kRecStride, nullptr};
   const ss::CoopEig ce{A.eig ? A.eig + ss::rec_base(0, 1, ss::EigRec<N>::NELEM, m) : nullptr, ss::kRecStride};
-  ss::calc_matrices_lw<N, N, 0>(g1, g2, b, A.dsc ? dsc : nullptr, A.dz, w, A.eig ? &ce : nullptr);
+  bool done16 = false;
+  if constexpr (ss::r16_layer(N, true))
+    done16 = A.eig && ss::rec_elem_load(ce.rec, ce.stride, ss::EigRec<N>::STATUS) > 0.5;   // k_unit_layer16 wrote the record
+  if (!done16) ss::calc_matrices_lw<N, N, 0>(g1, g2, b, A.dsc ? dsc : nullptr, A.dz, w, A.eig ? &ce : nullptr);
   __threadfence();
   rec_to_stack<N, N>(rec, Rec::R, A.o0, A.nmat, m);
   rec_to_stack<N, N>(rec, Rec::T, A.o1, A.nmat, m);
@@ -142,18 +151,69 @@ __global__ void __launch_bounds__(64) k_unit_lw(const UnitArgs A) {
   rec_to_stack<N, 1>(rec, Rec::ISRC, A.o4, A.nmat, m);
 }
 
-// the two extra launches of the cooperative eigen route (ss_eigen_coop.hpp): W of every problem,
-// then the Jacobi iteration on 4 lanes per problem
-template <int N>
-__global__ void __launch_bounds__(64) k_unit_coop_pre(const UnitArgs A) {
+// The launches of the cooperative route (orders 7..16), as launch_ns (ss_inst_body.hpp) runs them:
+// first pass (one lane per problem: structure check, the Gamma matrices and - shortwave - the
+// direct-beam part into the records), Cholesky factors on DPP rows, Jacobi, layer matrices on DPP rows
+template <int N, int D, bool LW>
+__global__ void __launch_bounds__(64) k_unit_coop_first(const UnitArgs A) {
   const int m = blockIdx.x * 64 + threadIdx.x;
   if (m >= A.nmat) return;
+  using ER = ss::EigRec<N>;
   double g1[N * N], g2[N * N], dsc[N];
   load_stack<N, N>(A.g1, A.nmat, m, g1);
   load_stack<N, N>(A.g2, A.nmat, m, g2);
   load_stack<N, 1>(A.dsc, A.nmat, m, dsc);
-  for (int k = 0; k < N * N; ++k) g1[k] = g1[k] - g2[k];
-  ss::coop_eig_pre<N>(g1, g2, dsc, A.eig + ss::rec_base(0, 1, ss::EigRec<N>::NELEM, m), ss::kRecStride);
+  double* erec = A.eig + ss::rec_base(0, 1, ER::NELEM, m);
+  constexpr long st = ss::kRecStride;
+  double size;
+  bool ok = ss::coop_eig_check<N>(g1, g2, dsc, size);
+  if (!LW && !A.dsc0) ok = false;
+  ss::rec_elem_store(erec, st, ER::STATUS, ok ? 1.0 : 0.0);
+  if (!ok) return;
+  ss::rec_elem_store(erec, st, 1, A.dz);
+  ss::rec_elem_store(erec, st, ER::EV, size);
+  for (int i = 0; i < N; ++i) {
+    for (int j = 0; j < N; ++j) {
+      ss::rec_elem_store(erec, st, ER::G1 + i * N + j, g1[i + j * N]);
+      ss::rec_elem_store(erec, st, ER::G2 + i * N + j, g2[i + j * N]);
+    }
+    ss::rec_elem_store(erec, st, ER::VEC + i, dsc[i]);
+  }
+  if constexpr (LW) {
+    double b[N];
+    load_stack<N, 1>(A.b, A.nmat, m, b);
+    for (int i = 0; i < N; ++i) ss::rec_elem_store(erec, st, ER::VEC + N + i, b[i]);
+  } else {
+    double g0[D * D], g3[N * D], dsc0[D], mu[D], G0[D * D], G0inv[D * D], emu[D];
+    load_stack<D, D>(A.g0, A.nmat, m, g0);
+    load_stack<N, D>(A.g3, A.nmat, m, g3);
+    load_stack<D, 1>(A.dsc0, A.nmat, m, dsc0);
+    const ss::RecWriter w{A.rec + ss::rec_base(0, 1, ss::SwRec<N, D>::NELEM, m), st, nullptr};
+    ss::sw_direct_part<N, D>(g0, dsc0, A.dz, w, mu, G0, G0inv, emu);
+    for (int i = 0; i < N; ++i)
+      for (int r = 0; r < D; ++r) ss::rec_elem_store(erec, st, ER::vg3() + i * D + r, g3[i + r * N]);
+    for (int r = 0; r < D; ++r) {
+      ss::rec_elem_store(erec, st, ER::vmu(D) + r, mu[r]);
+      ss::rec_elem_store(erec, st, ER::vemu(D) + r, emu[r]);
+    }
+    for (int k = 0; k < D * D; ++k) {
+      ss::rec_elem_store(erec, st, ER::vg0(D) + k, G0[k]);
+      ss::rec_elem_store(erec, st, ER::vg0inv(D) + k, G0inv[k]);
+    }
+  }
+}
+// STEP 0: Cholesky factors (r16::eig_pre), STEP 1: layer matrices (r16::layer_lw / layer_sw); 4 problems per wave
+template <int N, int D, bool LW, int STEP>
+__global__ void __launch_bounds__(64, 2) k_unit_row16(const UnitArgs A) {
+  const int m = blockIdx.x * (64 / ss::r16::kRow) + (int)threadIdx.x / ss::r16::kRow;
+  if (m >= A.nmat) return;
+  if constexpr (ss::coop_order(N)) {
+    double* erec = A.eig + ss::rec_base(0, 1, ss::EigRec<N>::NELEM, m);
+    if (!(ss::rec_elem_load(erec, ss::kRecStride, ss::EigRec<N>::STATUS) > 0.5)) return;
+    if constexpr (STEP == 0) ss::r16::eig_pre<N>(erec, ss::kRecStride, nullptr);
+    else if constexpr (LW) ss::r16::layer_lw<N>(erec, ss::kRecStride, A.rec + ss::rec_base(0, 1, ss::LwRec<N>::NELEM, m));
+    else ss::r16::layer_sw<N, D>(erec, ss::kRecStride, A.rec + ss::rec_base(0, 1, ss::SwRec<N, D>::NELEM, m));
+  }
 }
 template <int N>
 __global__ void __launch_bounds__(64) k_unit_coop_eig(const UnitArgs A) {
@@ -213,23 +273,26 @@ int finish(Stage& s, const char* what) {
   return SS_OK;
 }
 
-#define UNIT_COOP(NN)                                                                               \
+#define UNIT_COOP(NN, DD, LWF)                                                                       \
   if (ss::coop_order(NN) && A.dsc) {                                                                \
+    const unsigned g16 = (unsigned)((nmat + 3) / 4);                                                \
     A.eig = static_cast<double*>(s.raw(tiles * 64 * (size_t)ss::EigRec<NN>::NELEM * sizeof(double)));   \
-    if (s.err == hipSuccess) hipLaunchKernelGGL((k_unit_coop_pre<NN>), dim3(tiles), dim3(64), 0, 0, A); \
+    if (s.err == hipSuccess) hipLaunchKernelGGL((k_unit_coop_first<NN, DD, LWF>), dim3(tiles), dim3(64), 0, 0, A); \
+    if (s.err == hipSuccess) hipLaunchKernelGGL((k_unit_row16<NN, DD, LWF, 0>), dim3(g16), dim3(64), 0, 0, A);      \
     if (s.err == hipSuccess) hipLaunchKernelGGL((k_unit_coop_eig<NN>), dim3((nmat + 64 / ss::coop_lanes(NN) - 1) / (64 / ss::coop_lanes(NN))), dim3(64), 0, 0, A); \
+    if (s.err == hipSuccess) hipLaunchKernelGGL((k_unit_row16<NN, DD, LWF, 1>), dim3(g16), dim3(64), 0, 0, A);      \
   }
 #define UNIT_SW_CASE(NN, DD)                                                                        \
   if (ndiff == NN && ndir == DD) {                                                                  \
-    UNIT_COOP(NN)                                                                                   \
     A.rec = static_cast<double*>(s.raw(tiles * 64 * (size_t)ss::SwRec<NN, DD>::NELEM * sizeof(double))); \
+    UNIT_COOP(NN, DD, false)                                                                        \
     if (s.err == hipSuccess) hipLaunchKernelGGL((k_unit_sw<NN, DD>), dim3(tiles), dim3(64), 0, 0, A);   \
     launched = true;                                                                                \
   }
 #define UNIT_LW_CASE(NN)                                                                            \
   if (norder == NN) {                                                                               \
-    UNIT_COOP(NN)                                                                                   \
     A.rec = static_cast<double*>(s.raw(tiles * 64 * (size_t)ss::LwRec<NN>::NELEM * sizeof(double)));   \
+    UNIT_COOP(NN, 1, true)                                                                          \
     if (s.err == hipSuccess) hipLaunchKernelGGL((k_unit_lw<NN>), dim3(tiles), dim3(64), 0, 0, A);       \
     launched = true;                                                                                \
   }
