@@ -805,12 +805,17 @@ class Plan {
           for (size_t first = 0; first < c.cols.size(); first += chunk) {
             const size_t count = std::min(chunk, c.cols.size() - first);
             const int chunk_maxlay = h_nlay[c.cols[first]];   // sorted descending
-            // Orders above SS_UNROLL_MAX keep their matrices in the hardware scratch
-            // (tens of KB per lane, GBs per queue): concurrent queues then fight over
-            // it (measured 5.5e5 -> 3.2e5 columns/s with four streams at n = 12), so
-            // those classes stay on the first stream.
-            const bool big_order = c.key.nreg * c.key.ns > SS_UNROLL_MAX;
-            const int pipe = big_order ? 0 : nlaunched++ % npipes;
+            // Orders above SS_UNROLL_MAX that the row-of-16 kernels do not take (above 16) keep
+            // their matrices in the hardware scratch (tens of KB per lane, GBs per queue):
+            // concurrent queues then fight over it (measured 5.5e5 -> 3.2e5 columns/s with four
+            // streams at n = 12 in the one-lane form), so those classes stay on the first stream.
+            // The cooperative orders (7..16) still carry the one-lane second pass with its 17 KB of
+            // scratch per lane for the units the cooperative route declines: two queues hold that
+            // (3.1e6 -> 3.5e6 columns/s at n = 12), four exhaust the runtime's scratch budget.
+            const int order = c.key.nreg * c.key.ns;
+            const bool big_order = order > SS_UNROLL_MAX && !coop_order(order);
+            const int pipes_here = coop_order(order) ? std::min(npipes, 2) : npipes;
+            const int pipe = big_order ? 0 : nlaunched++ % pipes_here;
             Launch L = make_launch(c, lw != 0, first, count, chunk_maxlay, pipe);
             be.launch_solver(c.key, lw != 0, L, timers, pipe);
           }
