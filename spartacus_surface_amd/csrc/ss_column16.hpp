@@ -105,7 +105,8 @@ SS_HD void column_up_lw(const Launch& L, int cu) {
   for (int jlay = 0; jlay < nlay; ++jlay) {
     const double* lrec = L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu);
     double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
-    rv R[N], T[N], Abe[N], Sbe;
+    // (R turns into a_below in place and T into P: five matrices live at the peak)
+    rv R[N], T[N], Sbe;
     load_colmajor<N, N>(lrec, st, LRec::R, R);
     load_colmajor<N, N>(lrec, st, LRec::T, T);
     const rv Sl = load_vec<N>(lrec, st, LRec::SRC);
@@ -116,35 +117,31 @@ SS_HD void column_up_lw(const Launch& L, int cu) {
       SS_UNROLL_FULL
       for (int j = 0; j < N; ++j) Den.a[j] = select(lane_eq(j), rv(1.0), rv(0.0)) - Den.a[j];
       lu_factor<N>(Den);
+      // Den^-1 (source_above + a_above source_lay) and Den^-1 (R source_above + source_lay)
+      rv v[2];
+      v[0] = Sab;
+      mat_vec<N, true>(Aab, Sl, v[0]);
+      v[1] = Sl;
+      mat_vec<N, true>(R, Sab, v[1]);
+      lu_solve<N, 2>(Den, v);
+      store_vec<N>(crec, st, CRec::RSD, v[1]);
       {
         // a_below = R + T Den^-1 (a_above T)
         rv X[N];
         mul<N, N, false, false>(Aab, nullptr, T, X);
         lu_solve<N, N>(Den, X);
-        SS_UNROLL_FULL
-        for (int j = 0; j < N; ++j) Abe[j] = R[j];
-        mul<N, N, true, false>(T, nullptr, X, Abe);
-        store_colmajor<N, N>(crec, st, CRec::ABE, Abe);
+        mul<N, N, true, false>(T, nullptr, X, R);
+        store_colmajor<N, N>(crec, st, CRec::ABE, R);
       }
-      {
-        // Eq. 34: source_below = source_lay + T Den^-1 (source_above + a_above source_lay)
-        rv v[1];
-        v[0] = Sab;
-        mat_vec<N, true>(Aab, Sl, v[0]);
-        lu_solve<N, 1>(Den, v);
-        Sbe = Sl;
-        mat_vec<N, true>(T, v[0], Sbe);
-        store_vec<N>(crec, st, CRec::SBE, Sbe);
-        // Den^-1 (R source_above + source_lay)
-        v[0] = Sl;
-        mat_vec<N, true>(R, Sab, v[0]);
-        lu_solve<N, 1>(Den, v);
-        store_vec<N>(crec, st, CRec::RSD, v[0]);
-      }
+      // Eq. 34: source_below = source_lay + T Den^-1 (source_above + a_above source_lay)
+      Sbe = Sl;
+      mat_vec<N, true>(T, v[0], Sbe);
+      store_vec<N>(crec, st, CRec::SBE, Sbe);
       // P = Den^-1 T
       lu_solve<N, N>(Den, T);
       store_colmajor<N, N>(crec, st, CRec::PDN, T);
     }
+    const rv* Abe = R;
     // overlap to the base of the layer above, or to the free atmosphere (forest :495-506, urban :583-626)
     {
       double U[NREG * DB], V[DB * NREG];
@@ -214,7 +211,8 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
   for (int jlay = 0; jlay < c.nlay; ++jlay) {
     const double* lrec = L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu);
     double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
-    rv R[N], T[N], Abe[N], Dbe[D];
+    // (R turns into a_below in place and T into P: five matrices live at the peak)
+    rv R[N], T[N], Dbe[D];
     load_colmajor<N, N>(lrec, st, LRec::R, R);
     load_colmajor<N, N>(lrec, st, LRec::T, T);
     {
@@ -224,22 +222,13 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
       SS_UNROLL_FULL
       for (int j = 0; j < N; ++j) Den.a[j] = select(lane_eq(j), rv(1.0), rv(0.0)) - Den.a[j];
       lu_factor<N>(Den);
+      rv Y[D];
       {
-        // a_below = R + T Den^-1 (a_above T)
-        rv X[N];
-        mul<N, N, false, false>(Aab, nullptr, T, X);
-        lu_solve<N, N>(Den, X);
-        SS_UNROLL_FULL
-        for (int j = 0; j < N; ++j) Abe[j] = R[j];
-        mul<N, N, true, false>(T, nullptr, X, Abe);
-        store_colmajor<N, N>(crec, st, CRec::ABE, Abe);
-      }
-      {
-        // d_below = S_up + T Den^-1 (d_above E + a_above S_dn);  Q = Den^-1 (R (d_above E) + S_dn)
+        // Q = Den^-1 (R (d_above E) + S_dn);  Y = Den^-1 (d_above E + a_above S_dn)
         double E[D * D];
         SS_UNROLL_FULL
         for (int k = 0; k < D * D; ++k) E[k] = rec_elem_load(lrec, st, LRec::EDIR + k);
-        rv S[D], Y[D], Q[D];
+        rv S[D], Q[D];
         load_colmajor<N, D>(lrec, st, LRec::SDN, S);
         SS_UNROLL_FULL
         for (int j = 0; j < D; ++j) {
@@ -254,14 +243,24 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
         store_colmajor<N, D>(crec, st, CRec::QDN, Q);
         mul<N, D, true, false>(Aab, nullptr, S, Y);
         lu_solve<N, D>(Den, Y);
-        load_colmajor<N, D>(lrec, st, LRec::SUP, Dbe);
-        mul<N, D, true, false>(T, nullptr, Y, Dbe);
-        store_colmajor<N, D>(crec, st, CRec::DBE, Dbe);
       }
+      {
+        // a_below = R + T Den^-1 (a_above T)
+        rv X[N];
+        mul<N, N, false, false>(Aab, nullptr, T, X);
+        lu_solve<N, N>(Den, X);
+        mul<N, N, true, false>(T, nullptr, X, R);
+        store_colmajor<N, N>(crec, st, CRec::ABE, R);
+      }
+      // d_below = S_up + T Y
+      load_colmajor<N, D>(lrec, st, LRec::SUP, Dbe);
+      mul<N, D, true, false>(T, nullptr, Y, Dbe);
+      store_colmajor<N, D>(crec, st, CRec::DBE, Dbe);
       // P = Den^-1 T
       lu_solve<N, N>(Den, T);
       store_colmajor<N, N>(crec, st, CRec::PDN, T);
     }
+    const rv* Abe = R;
     // overlap to the base of the layer above, or to the free atmosphere (forest :495-503, urban :627-653)
     {
       double U[NREG * DB], V[DB * NREG];

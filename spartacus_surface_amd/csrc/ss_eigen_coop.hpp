@@ -108,6 +108,20 @@ SS_HD void rec_elem_store(double* rec, long stride, int e, double v) {
   rec[(long)(e & ~1) * stride + (e & 1)] = v;
 }
 
+// A column-major N x N matrix of a lane into the ROW-major block "off" (even) of a record: 16-byte
+// pairs along a row where the order is even (every row then starts at an even element)
+template <int N>
+SS_HD void rec_store_rowmajor(double* rec, long stride, int off, const double* a) {
+  for (int i = 0; i < N; ++i) {
+    if constexpr (N % 2 == 0) {
+      for (int j = 0; j < N; j += 2)
+        rec_pair_store(rec + (long)(off + i * N + j) * stride, SS_E(a, i, j, N), SS_E(a, i, j + 1, N));
+    } else {
+      for (int j = 0; j < N; ++j) rec_elem_store(rec, stride, off + i * N + j, SS_E(a, i, j, N));
+    }
+  }
+}
+
 // ---- pass 1 of the layer kernel, one lane per problem: is the structure there? ----
 // dscale = D: both D^-1 (G1 - G2) D and D^-1 G2 D must be symmetric.  Returns the
 // largest element of the two scaled matrices in "size" (the scale of the pivot test of the Cholesky

@@ -113,7 +113,7 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
   if constexpr (STAGE == 2 && r16_layer(NREG * NS, true)) {
     // units of the cooperative route had their layer matrices computed by the row-of-16 kernel
     if (rec_elem_load(L.eig + rec_base(jlay, L.maxlay, EigRec<NREG * NS>::NELEM, cu), kRecStride,
-                      EigRec<NREG * NS>::STATUS) > 0.5) return;
+                      EigRec<NREG * NS>::STATUS) != 0.0) return;      // 1: row-of-16 kernels, -1: first pass
   }
 
   // per-layer inputs from the input pack (ss_pack.hpp)
@@ -218,11 +218,9 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
         if (ok) {
           rec_elem_store(erec, kRecStride, 1, p.g.dz);
           rec_elem_store(erec, kRecStride, EigRec<N>::EV, size);
+          rec_store_rowmajor<N>(erec, kRecStride, EigRec<N>::G1, g1);
+          rec_store_rowmajor<N>(erec, kRecStride, EigRec<N>::G2, g2);
           for (int i = 0; i < N; ++i) {
-            for (int j = 0; j < N; ++j) {
-              rec_elem_store(erec, kRecStride, EigRec<N>::G1 + i * N + j, SS_E(g1, i, j, N));
-              rec_elem_store(erec, kRecStride, EigRec<N>::G2 + i * N + j, SS_E(g2, i, j, N));
-            }
             rec_elem_store(erec, kRecStride, EigRec<N>::VEC + i, dsc[i]);
             rec_elem_store(erec, kRecStride, EigRec<N>::VEC + N + i, b[i]);
           }
@@ -233,16 +231,19 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
         coop_eig_pre<N>(GD, g2, dsc, erec, kRecStride);
       }
     } else {
-      rec_elem_store(erec, kRecStride, EigRec<N>::STATUS, 0.0);
+      // a sub-problem (no vegetated or no clear region): with the row-of-16 kernels it is done right
+      // here (status -1: nothing left for anybody), else the second pass does it
+      rec_elem_store(erec, kRecStride, EigRec<N>::STATUS, r16_layer(N, true) ? -1.0 : 0.0);
     }
-    if (L.eigen_fail && !(rec_elem_load(erec, kRecStride, EigRec<N>::STATUS) > 0.5)) {
+    const double status = rec_elem_load(erec, kRecStride, EigRec<N>::STATUS);
+    if (L.eigen_fail && status > -0.5 && !(status > 0.5)) {
 #if defined(__HIP_DEVICE_COMPILE__)
       atomicAdd(L.eigen_fail + kSlotOneLaneUnits, 1ULL);
 #else
       L.eigen_fail[kSlotOneLaneUnits] += 1ULL;
 #endif
     }
-    return;
+    if (!(status < -0.5)) return;
   }
   const CoopEig ce{erec, kRecStride};
   if (NREG == 1 || p.g.veg_fraction <= L.cfg.min_vegetation_fraction) {
@@ -258,7 +259,8 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
     get_block<N, NV, NV, IV, IV>(g2, s2);
     ierr = calc_matrices_lw<N, NV, IV>(s1, s2, b + IV, dsc + IV, p.g.dz, w);
   } else {
-    ierr = calc_matrices_lw<N, N, 0>(g1, g2, b, dsc, p.g.dz, w, STAGE == 2 ? &ce : nullptr);
+    if constexpr (STAGE == 1) ierr = 0;     // (full problems of the first pass went the cooperative way above)
+    else ierr = calc_matrices_lw<N, N, 0>(g1, g2, b, dsc, p.g.dz, w, STAGE == 2 ? &ce : nullptr);
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ierr != 0 && L.eigen_fail) atomicAdd(L.eigen_fail, 1ULL);
