@@ -471,7 +471,7 @@ struct HipBackend {
       else fn = key.nreg == 1 ? ss::launch_lw_urban_r1 : key.nreg == 2 ? ss::launch_lw_urban_r2 : ss::launch_lw_urban_r3;
     }
     hipEvent_t ev[4] = {t.next(), t.next(), t.next(), t.next()};
-    const int rc = fn(key.ns, L, pipe_stream(pipe), ev);
+    const int rc = fn(key.ns, L, pipe_stream(pipe), ev, pipe_stream(0));
     if (rc != 0) {
       // SS_LAUNCH_BAD_RECORD: the plan's record sizes disagree with the kernels' (a build
       // inconsistency); anything else is the hipError_t of the failing launch / event record

@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_DOWN)) k_
 #define SS_TRY(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 template <int NS>
-int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev) {
+int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev, hipStream_t fallback) {
   {
     // the plan sized the scratch with its own formula: it must match the records
     constexpr int N = SS_INST_NREG * NS, D = SS_INST_NREG;
@@ -207,9 +207,25 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev) {
                          dim3(kBlock), 0, stream, L);
       SS_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0, 2>), glayer, dim3(kBlock), 0,
-                       stream, L);
-    SS_TRY(hipGetLastError());
+    if (fallback && fallback != stream) {
+      // second pass on the plan's fallback stream, between two events
+      hipEvent_t a, b;
+      SS_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+      SS_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+      SS_TRY(hipEventRecord(a, stream));
+      SS_TRY(hipStreamWaitEvent(fallback, a, 0));
+      hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0, 2>), glayer, dim3(kBlock), 0,
+                         fallback, L);
+      SS_TRY(hipGetLastError());
+      SS_TRY(hipEventRecord(b, fallback));
+      SS_TRY(hipStreamWaitEvent(stream, b, 0));
+      SS_TRY(hipEventDestroy(a));      // (released when the work that uses them has completed)
+      SS_TRY(hipEventDestroy(b));
+    } else {
+      hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0, 2>), glayer, dim3(kBlock), 0,
+                         stream, L);
+      SS_TRY(hipGetLastError());
+    }
   } else {
     hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), glayer, dim3(kBlock), 0,
                        stream, L);
@@ -243,20 +259,20 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev) {
 
 }  // namespace
 
-int SS_INST_NAME(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev) {
+int SS_INST_NAME(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev, hipStream_t fallback) {
 #ifdef SS_ONLY_NS   // experiment builds: a single stream count per unit
-  if (ns == SS_ONLY_NS) return launch_ns<SS_ONLY_NS>(L, stream, ev);
+  if (ns == SS_ONLY_NS) return launch_ns<SS_ONLY_NS>(L, stream, ev, fallback);
   return (int)hipErrorInvalidValue;
 #else
   switch (ns) {
-    case 1: return launch_ns<1>(L, stream, ev);
-    case 2: return launch_ns<2>(L, stream, ev);
-    case 3: return launch_ns<3>(L, stream, ev);
-    case 4: return launch_ns<4>(L, stream, ev);
-    case 5: return launch_ns<5>(L, stream, ev);
-    case 6: return launch_ns<6>(L, stream, ev);
-    case 7: return launch_ns<7>(L, stream, ev);
-    case 8: return launch_ns<8>(L, stream, ev);
+    case 1: return launch_ns<1>(L, stream, ev, fallback);
+    case 2: return launch_ns<2>(L, stream, ev, fallback);
+    case 3: return launch_ns<3>(L, stream, ev, fallback);
+    case 4: return launch_ns<4>(L, stream, ev, fallback);
+    case 5: return launch_ns<5>(L, stream, ev, fallback);
+    case 6: return launch_ns<6>(L, stream, ev, fallback);
+    case 7: return launch_ns<7>(L, stream, ev, fallback);
+    case 8: return launch_ns<8>(L, stream, ev, fallback);
     default: return (int)hipErrorInvalidValue;
   }
 #endif

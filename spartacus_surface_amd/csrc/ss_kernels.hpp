@@ -19,10 +19,14 @@ constexpr int kBlock = 64;   // one wavefront per workgroup: no LDS sharing, no 
 // recorded before, between and after the three kernels.  Returns 0, the hipError_t
 // of the first failing launch / event record, or kLaunchBadRecord when the plan's
 // scratch record sizes disagree with the kernels' record types (nothing launched).
+// "fallback": the stream the one-lane second pass of the cooperative orders runs on (ordered
+// with "stream" by events): that kernel keeps 17 KB of scratch per lane for the units the
+// cooperative route declines, and the runtime backs scratch per queue - one queue of a plan
+// carries it, whatever the number of pipes.
 constexpr int kLaunchBadRecord = -1;
-using SolverLauncher = int (*)(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev);
+using SolverLauncher = int (*)(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev, hipStream_t fallback);
 
-#define SS_DECL_LAUNCHER(name) int name(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev)
+#define SS_DECL_LAUNCHER(name) int name(int ns, const Launch& L, hipStream_t stream, hipEvent_t* ev, hipStream_t fallback)
 SS_DECL_LAUNCHER(launch_sw_forest_r2);
 SS_DECL_LAUNCHER(launch_sw_forest_r3);
 SS_DECL_LAUNCHER(launch_sw_urban_r1);

@@ -809,13 +809,12 @@ class Plan {
             // their matrices in the hardware scratch (tens of KB per lane, GBs per queue):
             // concurrent queues then fight over it (measured 5.5e5 -> 3.2e5 columns/s with four
             // streams at n = 12 in the one-lane form), so those classes stay on the first stream.
-            // The cooperative orders (7..16) still carry the one-lane second pass with its 17 KB of
-            // scratch per lane for the units the cooperative route declines: two queues hold that
-            // (3.1e6 -> 3.5e6 columns/s at n = 12), four exhaust the runtime's scratch budget.
+            // (The cooperative orders, 7..16, keep their one-lane second pass - 17 KB of scratch per lane
+            // for the units the cooperative route declines - on the first stream whatever their pipe:
+            // launch_ns, "fallback".)
             const int order = c.key.nreg * c.key.ns;
             const bool big_order = order > SS_UNROLL_MAX && !coop_order(order);
-            const int pipes_here = coop_order(order) ? std::min(npipes, 2) : npipes;
-            const int pipe = big_order ? 0 : nlaunched++ % pipes_here;
+            const int pipe = big_order ? 0 : nlaunched++ % npipes;
             Launch L = make_launch(c, lw != 0, first, count, chunk_maxlay, pipe);
             be.launch_solver(c.key, lw != 0, L, timers, pipe);
           }

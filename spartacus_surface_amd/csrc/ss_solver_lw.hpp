@@ -231,9 +231,11 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
         coop_eig_pre<N>(GD, g2, dsc, erec, kRecStride);
       }
     } else {
-      // a sub-problem (no vegetated or no clear region): with the row-of-16 kernels it is done right
-      // here (status -1: nothing left for anybody), else the second pass does it
-      rec_elem_store(erec, kRecStride, EigRec<N>::STATUS, r16_layer(N, true) ? -1.0 : 0.0);
+      // a sub-problem: the clear-sky one (order NS, registers) is done right here when the row-of-16
+      // kernels take the full problems (status -1: nothing left for anybody); the vegetation-only one
+      // (order N - NS, scratch-resident matrices) and everything else waits for the second pass
+      const bool clear_only = (NREG == 1) || (p.g.veg_fraction <= L.cfg.min_vegetation_fraction);
+      rec_elem_store(erec, kRecStride, EigRec<N>::STATUS, (r16_layer(N, true) && clear_only && NS <= SS_UNROLL_MAX) ? -1.0 : 0.0);
     }
     const double status = rec_elem_load(erec, kRecStride, EigRec<N>::STATUS);
     if (L.eigen_fail && status > -0.5 && !(status > 0.5)) {
@@ -251,13 +253,17 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
     get_block<N, NS, NS, 0, 0>(g1, s1);
     get_block<N, NS, NS, 0, 0>(g2, s2);
     ierr = calc_matrices_lw<N, NS, 0>(s1, s2, b, dsc, p.g.dz, w);
-  } else if (p.frac[0] <= L.cfg.min_vegetation_fraction) {
+  } else if (STAGE != 1 && p.frac[0] <= L.cfg.min_vegetation_fraction) {
     constexpr int NV = (NREG > 1) ? (NREG - 1) * NS : NS;
     constexpr int IV = (NREG > 1) ? NS : 0;
-    double s1[NV * NV], s2[NV * NV];
-    get_block<N, NV, NV, IV, IV>(g1, s1);
-    get_block<N, NV, NV, IV, IV>(g2, s2);
-    ierr = calc_matrices_lw<N, NV, IV>(s1, s2, b + IV, dsc + IV, p.g.dz, w);
+    if constexpr (STAGE != 1) {
+      double s1[NV * NV], s2[NV * NV];
+      get_block<N, NV, NV, IV, IV>(g1, s1);
+      get_block<N, NV, NV, IV, IV>(g2, s2);
+      ierr = calc_matrices_lw<N, NV, IV>(s1, s2, b + IV, dsc + IV, p.g.dz, w);
+    } else {
+      ierr = 0;
+    }
   } else {
     if constexpr (STAGE == 1) ierr = 0;     // (full problems of the first pass went the cooperative way above)
     else ierr = calc_matrices_lw<N, N, 0>(g1, g2, b, dsc, p.g.dz, w, STAGE == 2 ? &ce : nullptr);

@@ -234,9 +234,11 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
         coop_eig_pre<N>(GD, g2, dsc, erec, kRecStride);
       }
     } else {
-      // a sub-problem (no vegetated or no clear region): with the row-of-16 kernels it is done right
-      // here (status -1: nothing left for anybody), else the second pass does it
-      rec_elem_store(erec, kRecStride, EigRec<N>::STATUS, r16_layer(N, false) ? -1.0 : 0.0);
+      // a sub-problem: the clear-sky one (order NS, registers) is done right here when the row-of-16
+      // kernels take the full problems (status -1: nothing left for anybody); the vegetation-only one
+      // (order N - NS, scratch-resident matrices) and everything else waits for the second pass
+      const bool clear_only = (NREG == 1) || (g.veg_fraction <= L.cfg.min_vegetation_fraction);
+      rec_elem_store(erec, kRecStride, EigRec<N>::STATUS, (r16_layer(N, false) && clear_only && NS <= SS_UNROLL_MAX) ? -1.0 : 0.0);
     }
     const double status = rec_elem_load(erec, kRecStride, EigRec<N>::STATUS);
     if (L.eigen_fail && status > -0.5 && !(status > 0.5)) {
@@ -257,18 +259,22 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
     get_block<N, NS, NS, 0, 0>(g2, s2);
     get_block<N, NS, 1, 0, 0>(g3, s3);
     ierr = calc_matrices_sw<N, D, NS, 1, 0, 0>(s0, s1, s2, s3, dsc0, dsc, g.dz, w);
-  } else if (frac[0] <= L.cfg.min_vegetation_fraction) {
+  } else if (STAGE != 1 && frac[0] <= L.cfg.min_vegetation_fraction) {
     // vegetated regions only: (ns+1:n, 2:nreg)
     constexpr int NV = (NREG > 1) ? (NREG - 1) * NS : NS;
     constexpr int DV = (NREG > 1) ? NREG - 1 : 1;
     constexpr int IV = (NREG > 1) ? NS : 0;
     constexpr int RV = (NREG > 1) ? 1 : 0;
-    double s0[DV * DV], s1[NV * NV], s2[NV * NV], s3[NV * DV];
-    get_block<D, DV, DV, RV, RV>(g0, s0);
-    get_block<N, NV, NV, IV, IV>(g1, s1);
-    get_block<N, NV, NV, IV, IV>(g2, s2);
-    get_block<N, NV, DV, IV, RV>(g3, s3);
-    ierr = calc_matrices_sw<N, D, NV, DV, IV, RV>(s0, s1, s2, s3, dsc0 + RV, dsc + IV, g.dz, w);
+    if constexpr (STAGE != 1) {
+      double s0[DV * DV], s1[NV * NV], s2[NV * NV], s3[NV * DV];
+      get_block<D, DV, DV, RV, RV>(g0, s0);
+      get_block<N, NV, NV, IV, IV>(g1, s1);
+      get_block<N, NV, NV, IV, IV>(g2, s2);
+      get_block<N, NV, DV, IV, RV>(g3, s3);
+      ierr = calc_matrices_sw<N, D, NV, DV, IV, RV>(s0, s1, s2, s3, dsc0 + RV, dsc + IV, g.dz, w);
+    } else {
+      ierr = 0;
+    }
   } else {
     if constexpr (STAGE == 1) ierr = 0;     // (full problems of the first pass went the cooperative way above)
     else ierr = calc_matrices_sw<N, D, N, D, 0, 0>(g0, g1, g2, g3, dsc0, dsc, g.dz, w, STAGE == 2 ? &ce : nullptr);
