@@ -31,8 +31,11 @@ namespace {
 #define SS_MIN_WAVES_DOWN 1
 #endif
 
+// (first pass of the cooperative orders: scalars, element-wise Gamma stores and the small clear-sky
+// sub-problem - registers, not scratch: two waves per SIMD with 256 registers each)
 template <bool U, int R, int NS, bool LW, int STAGE = 0>
-__global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_LAYER)) k_layer(const Launch L) {
+__global__ void __launch_bounds__(kBlock, (STAGE == 1 && r16_layer(R * NS, LW)) ? 2 : SS_WAVES(R, NS, SS_MIN_WAVES_LAYER))
+    k_layer(const Launch L) {
 #ifndef SS_LAYER_GRID_2D
   // Block -> (tile of 64 column units, layer).  The per-layer inputs of a column
   // sit 8 * nlay bytes apart, so one block uses 8 bytes of every 128-byte line it
@@ -79,12 +82,20 @@ __global__ void __launch_bounds__(kBlock, 1) k_layer_up(const Launch L) {
   }
 }
 
+// Workgroups of the row-of-16 kernels: 128 threads = 8 units.  The records are tiled for one-lane
+// kernels ([element pair][lane][2]: the pairs of 8 neighbouring units make one 128-byte line), and
+// workgroups go to the 8 XCDs round-robin, each with its own L2: with 4 units per workgroup the two
+// halves of every line were fetched (and written) by two different L2s.
+constexpr int kBlock16 = 128;
+constexpr int kUnits16 = kBlock16 / r16::kRow;      // units per workgroup
+constexpr int kParts16 = kBlock / kUnits16;         // workgroups per tile of 64 units
+
 // Cholesky factors of the cooperative units (W, D L, -D L^-T of the eigen record) on the 16 lanes of a
 // DPP row, between the first pass of the layer kernel and the Jacobi kernel; block -> units as k_layer16
 template <int N>
-__global__ void __launch_bounds__(kBlock, 2) k_pre16(const Launch L) {
-  constexpr int UPB = kBlock / r16::kRow;
-  const int part = blockIdx.x % r16::kRow, tl = blockIdx.x / r16::kRow;
+__global__ void __launch_bounds__(kBlock16, 2) k_pre16(const Launch L) {
+  constexpr int UPB = kUnits16;
+  const int part = blockIdx.x % kParts16, tl = blockIdx.x / kParts16;
   const int tile = tl / L.maxlay, jlay = tl % L.maxlay;
   const int cu = tile * kBlock + part * UPB + (int)threadIdx.x / r16::kRow;
   if (cu >= L.ncu) return;
@@ -99,9 +110,9 @@ __global__ void __launch_bounds__(kBlock, 2) k_pre16(const Launch L) {
 // layer matrices of the cooperative units on the 16 lanes of a DPP row (ss_layer16.hpp):
 // block -> (tile of 64 units, layer, sixteenth of the tile); 4 units per wave
 template <int N, int D, bool LW>
-__global__ void __launch_bounds__(kBlock, 2) k_layer16(const Launch L) {
-  constexpr int UPB = kBlock / r16::kRow;          // units per block
-  const int part = blockIdx.x % r16::kRow, tl = blockIdx.x / r16::kRow;
+__global__ void __launch_bounds__(kBlock16, 2) k_layer16(const Launch L) {
+  constexpr int UPB = kUnits16;
+  const int part = blockIdx.x % kParts16, tl = blockIdx.x / kParts16;
   const int tile = tl / L.maxlay, jlay = tl % L.maxlay;
   const int cu = tile * kBlock + part * UPB + (int)threadIdx.x / r16::kRow;
   if (cu >= L.ncu) return;
@@ -118,8 +129,8 @@ __global__ void __launch_bounds__(kBlock, 2) k_layer16(const Launch L) {
 
 // upward sweep of the cooperative orders: one column unit on the 16 lanes of a DPP row (ss_column16.hpp)
 template <bool U, int R, int NS, bool LW>
-__global__ void __launch_bounds__(kBlock, 2) k_column16(const Launch L) {
-  const int cu = blockIdx.x * (kBlock / r16::kRow) + (int)threadIdx.x / r16::kRow;
+__global__ void __launch_bounds__(kBlock16, 2) k_column16(const Launch L) {
+  const int cu = blockIdx.x * kUnits16 + (int)threadIdx.x / r16::kRow;
   if (cu >= L.ncu) return;
   if constexpr (r16_layer(R * NS, LW)) {
     if constexpr (LW) r16::column_up_lw<U, R, NS>(L, cu);
@@ -138,8 +149,8 @@ __global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_COLUMN)) 
 
 // downward passes of the cooperative orders: one column unit (both passes) on the 16 lanes of a DPP row
 template <bool U, int R, int NS, bool LW>
-__global__ void __launch_bounds__(kBlock, 2) k_down16(const Launch L) {
-  const int cu = blockIdx.x * (kBlock / r16::kRow) + (int)threadIdx.x / r16::kRow;
+__global__ void __launch_bounds__(kBlock16, 2) k_down16(const Launch L) {
+  const int cu = blockIdx.x * kUnits16 + (int)threadIdx.x / r16::kRow;
   if (cu >= L.ncu) return;
   if constexpr (r16_layer(R * NS, LW)) {
     if constexpr (LW) r16::column_down_lw<U, R, NS>(L, cu);
@@ -197,14 +208,14 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev, hipStream_t f
                        stream, L);
     SS_TRY(hipGetLastError());
     if constexpr (r16_layer(SS_INST_NREG * NS, SS_INST_LW != 0)) {
-      hipLaunchKernelGGL((k_pre16<SS_INST_NREG * NS>), dim3(gx * (unsigned)L.maxlay * r16::kRow), dim3(kBlock), 0, stream, L);
+      hipLaunchKernelGGL((k_pre16<SS_INST_NREG * NS>), dim3(gx * (unsigned)L.maxlay * kParts16), dim3(kBlock16), 0, stream, L);
       SS_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL((k_eig_coop<SS_INST_NREG * NS>), dim3(gx * (unsigned)L.maxlay * coop_lanes(SS_INST_NREG * NS)), dim3(kBlock), 0, stream, L);
     SS_TRY(hipGetLastError());
     if constexpr (r16_layer(SS_INST_NREG * NS, SS_INST_LW != 0)) {
-      hipLaunchKernelGGL((k_layer16<SS_INST_NREG * NS, SS_INST_NREG, SS_INST_LW != 0>), dim3(gx * (unsigned)L.maxlay * r16::kRow),
-                         dim3(kBlock), 0, stream, L);
+      hipLaunchKernelGGL((k_layer16<SS_INST_NREG * NS, SS_INST_NREG, SS_INST_LW != 0>), dim3(gx * (unsigned)L.maxlay * kParts16),
+                         dim3(kBlock16), 0, stream, L);
       SS_TRY(hipGetLastError());
     }
     if (fallback && fallback != stream) {
@@ -233,9 +244,9 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev, hipStream_t f
   }
   if (ev) SS_TRY(hipEventRecord(ev[1], stream));
   if constexpr (r16_layer(SS_INST_NREG * NS, SS_INST_LW != 0)) {
-    constexpr unsigned upb = kBlock / r16::kRow;
+    constexpr unsigned upb = kUnits16;
     hipLaunchKernelGGL((k_column16<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>),
-                       dim3(((unsigned)L.ncu + upb - 1) / upb), dim3(kBlock), 0, stream, L);
+                       dim3(((unsigned)L.ncu + upb - 1) / upb), dim3(kBlock16), 0, stream, L);
   } else {
     hipLaunchKernelGGL((k_column<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx), dim3(kBlock), 0,
                        stream, L);
@@ -243,9 +254,9 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev, hipStream_t f
   SS_TRY(hipGetLastError());
   if (ev) SS_TRY(hipEventRecord(ev[2], stream));
   if constexpr (r16_layer(SS_INST_NREG * NS, SS_INST_LW != 0)) {
-    constexpr unsigned upb = kBlock / r16::kRow;
+    constexpr unsigned upb = kUnits16;
     hipLaunchKernelGGL((k_down16<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>),
-                       dim3(((unsigned)L.ncu + upb - 1) / upb), dim3(kBlock), 0, stream, L);
+                       dim3(((unsigned)L.ncu + upb - 1) / upb), dim3(kBlock16), 0, stream, L);
     SS_TRY(hipGetLastError());
   } else {
     const unsigned gd = (unsigned)((2L * L.ncu + kBlock - 1) / kBlock);

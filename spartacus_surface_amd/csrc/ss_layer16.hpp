@@ -68,27 +68,30 @@ SS_HD bool cholesky_rows(rv* A, rv* Lr, double* rs, double thr) {
 
 // The factors the cooperative Jacobi kernel and the layer kernel need (what coop_eig_pre does on one
 // lane): with C = -D^-1 (G1 - G2) D = L L^T and M = C - 2 D^-1 G2 D = F F^T: W = F^T L, D L, -D L^-T.
-// In: G1, G2, dscale and the size of the scaled matrices (EV slot 0) as the first pass of the layer
-// kernel left them.  A unit whose matrices are not positive definite gets status 0 (second pass, general solver).
+// In: G1, G2 and dscale as the first pass of the layer kernel left them.  A unit whose matrices are not positive definite gets status 0 (second pass, general solver).
 template <int N>
 SS_HD void eig_pre(double* erec, long stride, unsigned long long* one_lane_units) {
   using ER = EigRec<N>;
-  const double size = rec_elem_load(erec, stride, ER::EV);
   const rv dsc = load_vec<N>(erec, stride, ER::VEC);
   double d[N];
   all_of<N>(dsc, d);
   const rv rd = select(lane_lt(N), 1.0 / (dsc + select(lane_lt(N), rv(0.0), rv(1.0))), rv(0.0));
   rv C[N], M[N];
+  double size = 0.0;      // scale of the pivot test: the largest element of the scaled matrices
   {
     rv g1[N], g2[N];
     load_rowmajor<N, N>(erec, stride, ER::G1, g1);
     load_rowmajor<N, N>(erec, stride, ER::G2, g2);
+    rv big = 0.0;      // largest |element| of the two scaled matrices in the own row
     SS_UNROLL_FULL
     for (int j = 0; j < N; ++j) {
       const rv sc = rd * d[j];
+      const rv sj = g2[j] * sc;
       C[j] = -((g1[j] - g2[j]) * sc);
-      M[j] = C[j] - 2.0 * (g2[j] * sc);
+      M[j] = C[j] - 2.0 * sj;
+      big = r_max(big, r_max(r_abs(C[j]), r_abs(sj)));
     }
+    static_for<0, N>([&](auto kc) { size = ss_max(size, bc<decltype(kc)::value>(big)); });
     // rows beyond the order: identity (their pivots are never used, but keep the arithmetic finite)
     SS_UNROLL_FULL
     for (int j = 0; j < N; ++j) {

@@ -65,6 +65,7 @@ SS_HD rv select(rm m, rv a, rv b) { return m ? a : b; }
 SS_HD rv r_sqrt(rv x) { return sqrt(x); }
 SS_HD rv r_exp(rv x) { return exp(x); }
 SS_HD rv r_max(rv a, double b) { return a > b ? a : b; }
+SS_HD rv r_abs(rv x) { return fabs(x); }
 template <class F>
 SS_HD rv gen(F&& f) { return f(lane()); }
 template <class F>
@@ -169,6 +170,8 @@ inline rv select(const rm& m, const rv& a, const rv& b) { rv r; for (int l = 0; 
 inline rv r_sqrt(const rv& x) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = std::sqrt(x.v[l]); return r; }
 inline rv r_exp(const rv& x) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = std::exp(x.v[l]); return r; }
 inline rv r_max(const rv& a, double b) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = a.v[l] > b ? a.v[l] : b; return r; }
+inline rv r_max(const rv& a, const rv& b) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = a.v[l] > b.v[l] ? a.v[l] : b.v[l]; return r; }
+inline rv r_abs(const rv& x) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = std::fabs(x.v[l]); return r; }
 template <class F>
 inline rv gen(F&& f) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = f(l); return r; }
 template <class F>

@@ -17,6 +17,7 @@
 #include "ss_layer_matrices.hpp"
 #include "ss_solver_sw.hpp"
 #include "ss_pack.hpp"
+#include "ss_row16.hpp"
 
 namespace ss {
 
@@ -99,6 +100,144 @@ SS_HD void lw_layer_props(const Launch& L, int lay, long sidx, LwLayerProps<URBA
   lw_layer_props<URBAN, NREG>(L, r, p);
 }
 
+// Element (I, J) of Gamma1 (as used: exchange / extinction part + Gamma2) and Gamma2 of a layer, the
+// expressions of layer_unit_lw below element by element, indices at compile time (forest :329-376,
+// urban :383-440): the first pass of the cooperative orders writes the matrices straight from these,
+// no N x N array of a lane in between (those arrays lived in scratch memory).
+template <bool URBAN, int NREG, int NS, int I, int J>
+SS_HD void lw_gamma_elem(const LG& lg, const LwLayerProps<URBAN, NREG>& p, const double* fx, double wall_ext,
+                         double wall_factor, double& g1, double& g2) {
+  constexpr int ri = I / NS, si = I % NS, rj = J / NS, sj = J % NS;
+  double e = 0.0;
+  if constexpr (I == J) {
+    SS_UNROLL_FULL
+    for (int jto = 0; jto < NREG; ++jto)
+      if (jto != ri) e = e - lg.tan_ang[si] * SS_E(fx, jto, ri, NREG);
+    if (URBAN) e = e - p.ext_reg[ri] / lg.mu[si] - lg.tan_ang[si] * p.f_wall[ri] * wall_ext;
+    else e = e - p.ext_reg[ri] / lg.mu[si];
+  } else if constexpr (si == sj && ri != rj) {
+    e = lg.tan_ang[si] * SS_E(fx, ri, rj, NREG);
+  }
+  g2 = 0.0;
+  if constexpr (ri == rj) {
+    if (URBAN)
+      g2 = 0.5 * (lg.weight[si] * p.ext_reg[ri] * p.ssa_reg[ri] / lg.mu[sj]
+                  + lg.vweight[si] * lg.tan_ang[sj] * p.f_wall[ri] * wall_factor);
+    else
+      g2 = (0.5 * lg.weight[si] / lg.mu[sj]) * p.ext_reg[ri] * p.ssa_reg[ri];
+  }
+  g1 = e + g2;
+}
+
+// Is the symmetric structure there?  D^-1 Gamma D is symmetric (D = sqrt(region fraction x weight x
+// mu)) when the lateral exchange is in detailed balance, fx(a, b) frac(b) = fx(b, a) frac(a), and every
+// region has a positive fraction: the in-region and wall scattering terms are symmetric by the
+// Legendre-Gauss table alone (ss_eigen_sym.hpp).  The element-wise test of the matrices
+// (coop_eig_check) says the same with N^2 loads.
+template <int NREG>
+SS_HD bool gamma_structure_ok(const double* frac, const double* fx) {
+  bool ok = true;
+  SS_UNROLL_FULL
+  for (int a = 0; a < NREG; ++a) {
+    if (!(frac[a] > 0.0)) ok = false;
+    SS_UNROLL_FULL
+    for (int b = a + 1; b < NREG; ++b) {
+      const double x = SS_E(fx, a, b, NREG) * frac[b], y = SS_E(fx, b, a, NREG) * frac[a];
+      if (!(fabs(x - y) <= 1.0e-10 * ss_max(fabs(x), fabs(y)))) ok = false;
+    }
+  }
+  return ok;
+}
+
+// First pass of the layer kernel for the orders the row-of-16 kernels take (k_layer<..., 1>): full
+// problems leave Gamma1, Gamma2, the scaling and the emission rates in the eigen record (status 1),
+// clear-sky sub-problems (order NS) are done here (status -1), the rest waits for the second pass (0).
+template <bool URBAN, int NREG, int NS, class W>
+SS_HD void layer_first_lw(const Launch& L, int cu, int jlay, const W& w) {
+  constexpr int N = NREG * NS;
+  using ER = EigRec<N>;
+  const Inputs& in = L.in;
+  const LG& lg = L.lg;
+  const int col = L.cols[cu / L.nspec];
+  const int jb = cu % L.nspec;
+  if (jlay >= in.nlay[col]) return;
+  LwLayerIn<URBAN, NREG> raw;
+  raw.load_pack(pack_rec(L, jlay, cu, kPackLw));
+  LwLayerProps<URBAN, NREG> p;
+  lw_layer_props<URBAN, NREG>(L, raw, p);
+  double fx[NREG * NREG];
+  exchange_rates<NREG>(p.frac, p.np, L.cfg.min_vegetation_fraction, fx);
+  const double wall_ext = 1.0;
+  const double wall_factor =
+      URBAN ? 1.0 - rec_pair_load(pack_rec(L, jlay, cu - jb, kPackLw) + 16 * kRecStride).x : 0.0;
+  double* erec = L.eig + rec_base(jlay, L.maxlay, ER::NELEM, cu);
+  constexpr long st = kRecStride;
+  // emission rate "b" and the symmetrising scaling, element i
+  auto b_of = [&](int jreg, int js) {
+    const double volume_emiss = p.frac[jreg] * (p.ext_reg[jreg] * (1.0 - p.ssa_reg[jreg]) * p.planck_reg[jreg]);
+    const double wall_emiss = URBAN ? p.npw[jreg] * lg.vadjustment * raw.wall_emission : 0.0;
+    return URBAN ? (lg.hweight[js] / lg.mu[js]) * volume_emiss + (0.5 * lg.vweight[js]) * wall_emiss
+                 : (lg.hweight[js] / lg.mu[js]) * volume_emiss;
+  };
+  const bool clear_only = (NREG == 1) || (p.g.veg_fraction <= L.cfg.min_vegetation_fraction);
+  const bool full = !clear_only && !(p.frac[0] <= L.cfg.min_vegetation_fraction);
+  double status = 0.0;
+  if (full) {
+    if (gamma_structure_ok<NREG>(p.frac, fx)) {
+      status = 1.0;
+      rec_elem_store(erec, st, 1, p.g.dz);
+      r16::static_for<0, N>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        r16::static_for<0, (N + 1) / 2>([&](auto jc) {
+          constexpr int J = 2 * decltype(jc)::value;
+          double a1, a2, c1 = 0.0, c2 = 0.0;
+          lw_gamma_elem<URBAN, NREG, NS, I, J>(lg, p, fx, wall_ext, wall_factor, a1, a2);
+          if constexpr (J + 1 < N) lw_gamma_elem<URBAN, NREG, NS, I, J + 1>(lg, p, fx, wall_ext, wall_factor, c1, c2);
+          if constexpr (N % 2 == 0) {
+            rec_pair_store(erec + (long)(ER::G1 + I * N + J) * st, a1, c1);
+            rec_pair_store(erec + (long)(ER::G2 + I * N + J) * st, a2, c2);
+          } else {
+            rec_elem_store(erec, st, ER::G1 + I * N + J, a1);
+            rec_elem_store(erec, st, ER::G2 + I * N + J, a2);
+            if constexpr (J + 1 < N) {
+              rec_elem_store(erec, st, ER::G1 + I * N + J + 1, c1);
+              rec_elem_store(erec, st, ER::G2 + I * N + J + 1, c2);
+            }
+          }
+        });
+        rec_elem_store(erec, st, ER::VEC + I, sqrt(p.frac[I / NS]) * lg.sqrt_wmu[I % NS]);
+        rec_elem_store(erec, st, ER::VEC + N + I, b_of(I / NS, I % NS));
+      });
+    }
+  } else if (clear_only && NS <= SS_UNROLL_MAX) {
+    status = -1.0;
+    double s1[NS * NS], s2[NS * NS], b[NS], dsc[NS];
+    r16::static_for<0, NS>([&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      r16::static_for<0, NS>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        lw_gamma_elem<URBAN, NREG, NS, I, J>(lg, p, fx, wall_ext, wall_factor, SS_E(s1, I, J, NS), SS_E(s2, I, J, NS));
+      });
+      b[I] = b_of(0, I);
+      dsc[I] = sqrt(p.frac[0]) * lg.sqrt_wmu[I];
+    });
+    const int ierr = calc_matrices_lw<N, NS, 0>(s1, s2, b, dsc, p.g.dz, w);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (ierr != 0 && L.eigen_fail) atomicAdd(L.eigen_fail, 1ULL);
+#else
+    if (ierr != 0 && L.eigen_fail) *L.eigen_fail += 1ULL;
+#endif
+  }
+  rec_elem_store(erec, st, ER::STATUS, status);
+  if (status == 0.0 && L.eigen_fail) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicAdd(L.eigen_fail + kSlotOneLaneUnits, 1ULL);
+#else
+    L.eigen_fail[kSlotOneLaneUnits] += 1ULL;
+#endif
+  }
+}
+
 // W: RecWriter (HBM layer record) or the FusedWriter of k_layer_up (ss_layer_matrices.hpp)
 // (STAGE: see layer_unit_sw)
 template <bool URBAN, int NREG, int NS, class W, int STAGE = 0>
@@ -110,6 +249,10 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
   const int col = L.cols[cu / L.nspec];
   const int jb = cu % L.nspec;
   if (jlay >= in.nlay[col]) return;
+  if constexpr (STAGE == 1 && r16_layer(NREG * NS, true)) {
+    layer_first_lw<URBAN, NREG, NS>(L, cu, jlay, w);
+    return;
+  }
   if constexpr (STAGE == 2 && r16_layer(NREG * NS, true)) {
     // units of the cooperative route had their layer matrices computed by the row-of-16 kernel
     if (rec_elem_load(L.eig + rec_base(jlay, L.maxlay, EigRec<NREG * NS>::NELEM, cu), kRecStride,

@@ -20,6 +20,7 @@
 #include "ss_layer_matrices.hpp"
 #include "ss_eigen_coop.hpp"
 #include "ss_pack.hpp"
+#include "ss_row16.hpp"
 
 namespace ss {
 
@@ -52,6 +53,211 @@ SS_HD void region_optics(double air_ext, double air_ssa, double veg_ext, double 
   }
 }
 
+// Everything of a layer the shortwave Gamma matrices are built from
+template <bool URBAN, int NREG>
+struct SwLayerProps {
+  LayerGeom g;
+  double cos_sza, sin0, tan0;
+  double frac[NREG], f_wall[NREG], ext_reg[NREG], ssa_reg[NREG], fx[NREG * NREG];
+  double wall_ext, wall_factor;
+};
+template <bool URBAN, int NREG>
+SS_HD void sw_layer_props(const Launch& L, double cos_in, const double* pk, SwLayerProps<URBAN, NREG>& p) {
+  p.cos_sza = URBAN ? ss_max(cos_in, 1.0e-6) : cos_in;
+  p.sin0 = 0.0;
+  if (URBAN) {
+    p.sin0 = sqrt(1.0 - p.cos_sza * p.cos_sza);
+    p.tan0 = p.sin0 / p.cos_sza;
+  } else {
+    p.tan0 = sqrt(1.0 - p.cos_sza * p.cos_sza) / ss_max(p.cos_sza, 1.0e-6);
+  }
+  LayerGeom& g = p.g;
+  g.dz = pk[0]; g.veg_fraction = pk[1]; g.veg_scale = pk[2]; g.veg_ext = pk[3];
+  g.veg_fsd = pk[4]; g.building_fraction = pk[5]; g.building_scale = pk[6]; g.veg_contact_fraction = pk[7];
+  double np[NREG], npw[NREG], od[NREG];
+  region_fractions<URBAN, false, NREG>(g.veg_fraction, g.building_fraction, p.frac);
+  norm_perimeters<URBAN, NREG>(L.cfg, g, np, npw);
+  exchange_rates<NREG>(p.frac, np, L.cfg.min_vegetation_fraction, p.fx);
+  od_scaling<NREG>(g.veg_fsd, od);
+  p.wall_ext = 0.0;
+  p.wall_factor = 0.0;
+  SS_UNROLL_FULL
+  for (int r = 0; r < NREG; ++r) p.f_wall[r] = 0.0;
+  if (URBAN) {
+    SS_UNROLL_FULL
+    for (int r = 0; r < NREG; ++r)
+      p.f_wall[r] = (p.frac[r] <= L.cfg.min_vegetation_fraction) ? 0.0 : npw[r] / (kPi * p.frac[r]);
+    const double wa = pk[10], wsf = pk[14];
+    p.wall_ext = 1.0 - wa * wsf;
+    p.wall_factor = wa * (1.0 - wsf);
+  }
+  region_optics<NREG>(pk[11], pk[12], g.veg_ext, pk[13], od, p.ext_reg, p.ssa_reg);
+}
+
+// Element (I, J) of Gamma1 (as used: + Gamma2) and Gamma2, the expressions of layer_unit_sw below
+// element by element with the indices at compile time (forest :329-387, urban :424-497)
+template <bool URBAN, int NREG, int NS, int I, int J>
+SS_HD void sw_gamma_elem(const LG& lg, const SwLayerProps<URBAN, NREG>& p, double& g1, double& g2) {
+  constexpr int ri = I / NS, si = I % NS, rj = J / NS, sj = J % NS;
+  double e = 0.0;
+  if constexpr (I == J) {
+    SS_UNROLL_FULL
+    for (int jto = 0; jto < NREG; ++jto)
+      if (jto != ri) e = e - lg.tan_ang[si] * SS_E(p.fx, jto, ri, NREG);
+    if (URBAN) e = e - p.ext_reg[ri] / lg.mu[si] - lg.tan_ang[si] * p.f_wall[ri] * p.wall_ext;
+    else e = e - p.ext_reg[ri] / lg.mu[si];
+  } else if constexpr (si == sj && ri != rj) {
+    e = lg.tan_ang[si] * SS_E(p.fx, ri, rj, NREG);
+  }
+  g2 = 0.0;
+  if constexpr (ri == rj) {
+    if (URBAN)
+      g2 = 0.5 * (lg.weight[si] * p.ext_reg[ri] * p.ssa_reg[ri] / lg.mu[sj]
+                  + lg.vweight[si] * lg.tan_ang[sj] * p.f_wall[ri] * p.wall_factor);
+    else
+      g2 = 0.5 * lg.weight[si] * p.ext_reg[ri] * p.ssa_reg[ri] / lg.mu[sj];
+  }
+  g1 = e + g2;
+}
+// Gamma0 (D x D) and the own-region column of Gamma3 (element (i, region of i); the rest is zero)
+template <bool URBAN, int NREG>
+SS_HD void sw_gamma0(const SwLayerProps<URBAN, NREG>& p, double* g0) {
+  constexpr int D = NREG;
+  mat_zero<D, D>(g0);
+  SS_UNROLL_FULL
+  for (int jfr = 0; jfr < NREG; ++jfr) {
+    SS_UNROLL_FULL
+    for (int jto = 0; jto < NREG; ++jto) {
+      if (jfr != jto) {
+        SS_E(g0, jfr, jfr, D) = SS_E(g0, jfr, jfr, D) - p.tan0 * SS_E(p.fx, jto, jfr, NREG);
+        SS_E(g0, jto, jfr, D) = p.tan0 * SS_E(p.fx, jto, jfr, NREG);
+      }
+    }
+  }
+  SS_UNROLL_FULL
+  for (int jreg = 0; jreg < NREG; ++jreg) {
+    if (URBAN)
+      SS_E(g0, jreg, jreg, D) = SS_E(g0, jreg, jreg, D) - p.ext_reg[jreg] / p.cos_sza
+                                - p.tan0 * p.f_wall[jreg] * p.wall_ext;
+    else
+      SS_E(g0, jreg, jreg, D) = SS_E(g0, jreg, jreg, D) - p.ext_reg[jreg] / p.cos_sza;
+  }
+}
+template <bool URBAN, int NREG>
+SS_HD double sw_gamma3_own(const LG& lg, const SwLayerProps<URBAN, NREG>& p, int jreg, int js) {
+  return URBAN ? 0.5 * (lg.weight[js] * p.ext_reg[jreg] * p.ssa_reg[jreg]
+                        + lg.vweight[js] * p.sin0 * p.f_wall[jreg] * p.wall_factor)
+               : 0.5 * lg.weight[js] * p.ext_reg[jreg] * p.ssa_reg[jreg];
+}
+
+template <int NF, int D, class W>
+SS_HD int sw_direct_part(const double* g0, const double* dsc0, double dz, const W& w, double* mu, double* G0,
+                         double* G0inv, double* emu);
+template <int NF, int DF, int N, int D, int I0, int R0, class W>
+SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2, const double* g3, const double* dsc0,
+                           const double* dsc, double dz, const W& w, const CoopEig* coop);
+template <int NREG>
+SS_HD bool gamma_structure_ok(const double* frac, const double* fx);
+
+// First pass of the layer kernel for the orders the row-of-16 kernels take (see layer_first_lw)
+template <bool URBAN, int NREG, int NS, class W>
+SS_HD void layer_first_sw(const Launch& L, int cu, int jlay, const W& w) {
+  constexpr int N = NREG * NS, D = NREG;
+  using ER = EigRec<N>;
+  const Inputs& in = L.in;
+  const LG& lg = L.lg;
+  const int col = L.cols[cu / L.nspec];
+  if (jlay >= in.nlay[col]) return;
+  double pk[kPackSw];
+  rec_load<kPackSw>(pack_rec(L, jlay, cu, kPackSw), kRecStride, 0, pk);
+  SwLayerProps<URBAN, NREG> p;
+  sw_layer_props<URBAN, NREG>(L, in.cos_sza[col], pk, p);
+  double* erec = L.eig + rec_base(jlay, L.maxlay, ER::NELEM, cu);
+  constexpr long st = kRecStride;
+  const bool clear_only = (NREG == 1) || (p.g.veg_fraction <= L.cfg.min_vegetation_fraction);
+  const bool full = !clear_only && !(p.frac[0] <= L.cfg.min_vegetation_fraction);
+  double status = 0.0;
+  int ierr = 0;
+  if (full) {
+    if (gamma_structure_ok<NREG>(p.frac, p.fx)) {
+      status = 1.0;
+      // The direct-beam part of the unit (D x D: one lane does it for its unit here, the 16 lanes of
+      // the row-of-16 kernel would each repeat it): int_dir and E go to the layer record, the
+      // eigen-decomposition of Gamma0 and what else ss_layer16.hpp needs to the eigen record
+      double g0[D * D], dsc0[D], mu[D], G0[D * D], G0inv[D * D], emu[D];
+      sw_gamma0<URBAN, NREG>(p, g0);
+      SS_UNROLL_FULL
+      for (int r = 0; r < D; ++r) dsc0[r] = sqrt(p.frac[r]);
+      ierr = sw_direct_part<N, D>(g0, dsc0, p.g.dz, w, mu, G0, G0inv, emu);
+      rec_elem_store(erec, st, 1, p.g.dz);
+      r16::static_for<0, N>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        r16::static_for<0, (N + 1) / 2>([&](auto jc) {
+          constexpr int J = 2 * decltype(jc)::value;
+          double a1, a2, c1 = 0.0, c2 = 0.0;
+          sw_gamma_elem<URBAN, NREG, NS, I, J>(lg, p, a1, a2);
+          if constexpr (J + 1 < N) sw_gamma_elem<URBAN, NREG, NS, I, J + 1>(lg, p, c1, c2);
+          if constexpr (N % 2 == 0) {
+            rec_pair_store(erec + (long)(ER::G1 + I * N + J) * st, a1, c1);
+            rec_pair_store(erec + (long)(ER::G2 + I * N + J) * st, a2, c2);
+          } else {
+            rec_elem_store(erec, st, ER::G1 + I * N + J, a1);
+            rec_elem_store(erec, st, ER::G2 + I * N + J, a2);
+            if constexpr (J + 1 < N) {
+              rec_elem_store(erec, st, ER::G1 + I * N + J + 1, c1);
+              rec_elem_store(erec, st, ER::G2 + I * N + J + 1, c2);
+            }
+          }
+        });
+        rec_elem_store(erec, st, ER::VEC + I, dsc0[I / NS] * lg.sqrt_wmu[I % NS]);
+        SS_UNROLL_FULL
+        for (int r = 0; r < D; ++r)
+          rec_elem_store(erec, st, ER::vg3() + I * D + r, (r == I / NS) ? sw_gamma3_own<URBAN, NREG>(lg, p, I / NS, I % NS) : 0.0);
+      });
+      SS_UNROLL_FULL
+      for (int r = 0; r < D; ++r) {
+        rec_elem_store(erec, st, ER::vmu(D) + r, mu[r]);
+        rec_elem_store(erec, st, ER::vemu(D) + r, emu[r]);
+      }
+      SS_UNROLL_FULL
+      for (int k = 0; k < D * D; ++k) {
+        rec_elem_store(erec, st, ER::vg0(D) + k, G0[k]);
+        rec_elem_store(erec, st, ER::vg0inv(D) + k, G0inv[k]);
+      }
+    }
+  } else if (clear_only && NS <= SS_UNROLL_MAX) {
+    status = -1.0;
+    // clear-sky region only: (1:ns, 1:1)
+    double g0[D * D], s0[1], s1[NS * NS], s2[NS * NS], s3[NS], dsc0[1], dsc[NS];
+    sw_gamma0<URBAN, NREG>(p, g0);
+    s0[0] = g0[0];
+    dsc0[0] = sqrt(p.frac[0]);
+    r16::static_for<0, NS>([&](auto ic) {
+      constexpr int I = decltype(ic)::value;
+      r16::static_for<0, NS>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        sw_gamma_elem<URBAN, NREG, NS, I, J>(lg, p, SS_E(s1, I, J, NS), SS_E(s2, I, J, NS));
+      });
+      s3[I] = sw_gamma3_own<URBAN, NREG>(lg, p, 0, I);
+      dsc[I] = dsc0[0] * lg.sqrt_wmu[I];
+    });
+    ierr = calc_matrices_sw<N, D, NS, 1, 0, 0>(s0, s1, s2, s3, dsc0, dsc, p.g.dz, w, nullptr);
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (ierr != 0 && L.eigen_fail) atomicAdd(L.eigen_fail, 1ULL);
+#else
+  if (ierr != 0 && L.eigen_fail) *L.eigen_fail += 1ULL;
+#endif
+  rec_elem_store(erec, st, ER::STATUS, status);
+  if (status == 0.0 && L.eigen_fail) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicAdd(L.eigen_fail + kSlotOneLaneUnits, 1ULL);
+#else
+    L.eigen_fail[kSlotOneLaneUnits] += 1ULL;
+#endif
+  }
+}
+
 // W: where the layer matrices go - RecWriter (HBM layer record, three-kernel form) or the
 // FusedWriter of k_layer_up (LDS / registers / column record).
 // STAGE (orders of the cooperative eigen-solver, ss_eigen_coop.hpp): 0 = everything here;
@@ -65,6 +271,10 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
   const int col = L.cols[cu / L.nspec];
   const int jb = cu % L.nspec;
   if (jlay >= in.nlay[col]) return;
+  if constexpr (STAGE == 1 && r16_layer(NREG * NS, false)) {
+    layer_first_sw<URBAN, NREG, NS>(L, cu, jlay, w);
+    return;
+  }
   if constexpr (STAGE == 2 && r16_layer(NREG * NS, false)) {
     // units of the cooperative route had their layer matrices computed by the row-of-16 kernel
     if (rec_elem_load(L.eig + rec_base(jlay, L.maxlay, EigRec<NREG * NS>::NELEM, cu), kRecStride,

@@ -4,7 +4,9 @@ profiles/<tag>_pmc.json (per kernel: registers, scratch, counters, derived
 per-column HBM traffic and executed fp64 flops) and refresh profiles/traffic.json,
 which bench.py reads to fill roofline.traffic.
 
-usage: tools/pmc_to_profile.py TAG NCOLUMNS   (NCOLUMNS = columns of the PMC runs)
+usage: tools/pmc_to_profile.py TAG NCOLUMNS [TRAFFIC_FILE [WORKLOAD]]
+       (NCOLUMNS = columns of the PMC runs; TRAFFIC_FILE defaults to profiles/traffic.json, which is
+        the C3 file bench.py reads - pass another name for other workloads)
 """
 import collections
 import csv
@@ -27,6 +29,8 @@ def newest_per_pass(root):
 
 
 tag, ncol = sys.argv[1], int(sys.argv[2])
+traffic_file = sys.argv[3] if len(sys.argv) > 3 else "profiles/traffic.json"
+workload = sys.argv[4] if len(sys.argv) > 4 else "C3"
 FAMILY = {("k_layer", "false"): "sw_layer", ("k_column", "false"): "sw_column",
           ("k_down", "false"): "sw_down", ("k_down", "true"): "lw_down",
           ("k_layer", "true"): "lw_layer", ("k_column", "true"): "lw_column",
@@ -35,8 +39,15 @@ FAMILY = {("k_layer", "false"): "sw_layer", ("k_column", "false"): "sw_column",
 
 
 def family_of(kernel, args):
-    # template arguments: <URBAN, NREG, NS, LW[, STAGE]>
+    # template arguments: <URBAN, NREG, NS, LW[, STAGE]>; the row-of-16 kernels of the orders 7..16:
+    # k_layer16<N, D, LW>, k_column16 / k_down16 as their one-lane namesakes, k_pre16<N> and
+    # k_eig_coop<N> serve both spectral regions ("layer_both")
     a = [x.strip() for x in args.split(",")]
+    if kernel == "k_layer16":
+        return "lw_layer" if a[2] == "true" else "sw_layer"
+    if kernel in ("k_pre16", "k_eig_coop"):
+        return "layer_both"
+    kernel = {"k_column16": "k_column", "k_down16": "k_down"}.get(kernel, kernel)
     return FAMILY.get((kernel, a[3] if len(a) > 3 else ""), kernel)
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 meta = {}
@@ -81,10 +92,10 @@ for k, c in sorted(agg.items()):
     t["write"] += write / ncol
     t["flops"] += d["derived"].get("fp64_flops_per_column_executed", 0.0)
 json.dump(out, open("profiles/%s_pmc.json" % tag, "w"), indent=1)
-json.dump({"source": "profiles/%s_pmc.json" % tag, "workload": "C3, %d columns" % ncol,
+json.dump({"source": "profiles/%s_pmc.json" % tag, "workload": "%s, %d columns" % (workload, ncol),
            "note": "HBM bytes per column per kernel family from FETCH_SIZE (x2, gfx950 correction of "
                    "MI355X_MICROARCH.md) + WRITE_SIZE; separate --pmc passes",
            "bytes_per_column": {f: t["fetch_x2"] + t["write"] for f, t in traffic.items()},
            "fp64_flops_per_column_executed": {f: t["flops"] for f, t in traffic.items()}},
-          open("profiles/traffic.json", "w"), indent=1)
-print(json.dumps(json.load(open("profiles/traffic.json")), indent=1))
+          open(traffic_file, "w"), indent=1)
+print(json.dumps(json.load(open(traffic_file)), indent=1))
