@@ -313,9 +313,12 @@ SS_HD void coop_eig_unit(double* rec, long stride, int q) {
     return v;
 #endif
   };
-  // a sweep without a rotation ends the iteration (the decision is taken on group-wide sums, so
-  // the lanes of a group agree on it)
+  // A rotation is applied where |g| > tol sqrt(a b).  The iteration ends after the first sweep in which
+  // no pair was above 1e-8 sqrt(a b) BEFORE its rotation: convergence is quadratic, so that sweep
+  // left every pair at the 1e-16 level and a further one would only confirm it (it was a seventh of
+  // the kernel).  The decision is taken on group-wide sums, so the lanes of a group agree on it.
   constexpr double tol = 4.0 * DBL_EPSILON;
+  constexpr double tol_last = 1.0e-8;
   for (int sweep = 0; sweep < 30; ++sweep) {
     SS_UNROLL_FULL
     for (int j = 0; j < N; ++j) {
@@ -335,7 +338,7 @@ SS_HD void coop_eig_unit(double* rec, long stride, int q) {
         apc = gsum(apc);
         const double app = nrm[p], acc = nrm[c];
         if (apc * apc > (tol * tol) * (app * acc)) {
-          rotated = true;
+          if (apc * apc > (tol_last * tol_last) * (app * acc)) rotated = true;
           // the smaller rotation angle (Rutishauser): t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)),
           // zeta = (acc - app) / (2 apc), written without the division by apc
           const double d = acc - app, g2 = apc + apc;

@@ -16,9 +16,35 @@
 namespace ss {
 namespace r16 {
 
+// Addresses.  Element e of a record sits at rec[(e & ~1) * stride + (e & 1)] (16-byte pairs, tiles of 64
+// units).  For the blocks the row-of-16 kernels move, the lane's row index i and the column j separate:
+//   column-major N x M, N and off even:  e = off + j N + i  ->  [(i & ~1) stride + (i & 1)]  +  (off + j N) stride
+//   row-major N x M,    M and off even:  e = off + i M + j  ->  [i M stride]  +  (off + (j & ~1)) stride + (j & 1)
+// i.e. ONE lane-dependent pointer per block plus compile-time offsets.  Left to itself the compiler keeps
+// a lane-dependent 64-bit offset per ELEMENT as a loop invariant (dozens of register pairs, spilled and
+// reloaded one dependent scratch round trip after the other in the sweeps); the device versions below
+// therefore form the lane pointer first and hide it from the optimiser (SS_PIN).  Rows beyond the
+// order load the last row's data (no branch) and are zeroed.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SS_R16_FAST_ADDR 1
+#endif
+
 // own row of a ROW-major N x M block of a record (rows beyond N: zero)
 template <int N, int M>
 SS_HD void load_rowmajor(const double* rec, long stride, int off, rv* A) {
+#ifdef SS_R16_FAST_ADDR
+  if constexpr (M % 2 == 0) {
+    const int i = lane(), ic = i < N ? i : N - 1;
+    const double* p = rec + (long)(ic * M) * stride;
+    SS_PIN(p);
+    SS_UNROLL_FULL
+    for (int j = 0; j < M; ++j) {
+      const double v = p[(long)(off + (j & ~1)) * stride + (j & 1)];
+      A[j] = i < N ? v : 0.0;
+    }
+    return;
+  }
+#endif
   SS_UNROLL_FULL
   for (int j = 0; j < M; ++j)
     A[j] = gen([&](int i) { return (i < N) ? rec_elem_load(rec, stride, off + i * M + j) : 0.0; });
@@ -26,19 +52,44 @@ SS_HD void load_rowmajor(const double* rec, long stride, int off, rv* A) {
 // own row of a COLUMN-major N x M block (element (i, j) at off + i + j N)
 template <int N, int M>
 SS_HD void load_colmajor(const double* rec, long stride, int off, rv* A) {
+#ifdef SS_R16_FAST_ADDR
+  if constexpr (N % 2 == 0) {
+    const int i = lane(), ic = i < N ? i : N - 1;
+    const double* p = rec + (long)(ic & ~1) * stride + (ic & 1);
+    SS_PIN(p);
+    SS_UNROLL_FULL
+    for (int j = 0; j < M; ++j) {
+      const double v = p[(long)(off + j * N) * stride];
+      A[j] = i < N ? v : 0.0;
+    }
+    return;
+  }
+#endif
   SS_UNROLL_FULL
   for (int j = 0; j < M; ++j)
     A[j] = gen([&](int i) { return (i < N) ? rec_elem_load(rec, stride, off + i + j * N) : 0.0; });
 }
 template <int N, int M>
 SS_HD void store_colmajor(double* rec, long stride, int off, const rv* A) {
+#ifdef SS_R16_FAST_ADDR
+  if constexpr (N % 2 == 0) {
+    const int i = lane();
+    if (i < N) {
+      double* p = rec + (long)(i & ~1) * stride + (i & 1);
+      SS_PIN(p);
+      SS_UNROLL_FULL
+      for (int j = 0; j < M; ++j) p[(long)(off + j * N) * stride] = A[j];
+    }
+    return;
+  }
+#endif
   SS_UNROLL_FULL
   for (int j = 0; j < M; ++j)
     each(A[j], [&](int i, double x) { if (i < N) rec_elem_store(rec, stride, off + i + j * N, x); });
 }
 template <int N>
 SS_HD rv load_vec(const double* rec, long stride, int off) {
-  return gen([&](int i) { return (i < N) ? rec_elem_load(rec, stride, off + i) : 0.0; });
+  return gen([&](int i) { const int ic = i < N ? i : N - 1; const double v = rec_elem_load(rec, stride, off + ic); return (i < N) ? v : 0.0; });
 }
 template <int N>
 SS_HD void store_vec(double* rec, long stride, int off, const rv& x) {
