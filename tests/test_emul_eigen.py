@@ -31,3 +31,23 @@ def test_symmetric_route_matches_general_solver(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     assert r.stdout.count("0 failures") == 4, r.stdout
+
+
+def test_row16_primitives_on_lane_packs(tmp_path):
+    """The dense-algebra primitives of the row-of-16 kernels (orders 7..16: product, unpivoted LU and
+    substitution, symmetric elimination with both Cholesky factors, sums over lanes) on packs of 16
+    'lanes' against plain loops (tests/emul/row16_check.cpp; the device runs the same source with
+    v_fmac_f64_dpp row_newbcast as the broadcast-multiply-add)."""
+    exe = str(tmp_path / "row16_check")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wno-unknown-pragmas", "-o", exe,
+                    os.path.join(HERE, "emul", "row16_check.cpp")], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    seen = 0
+    for line in out.splitlines():
+        n, name, val = line.split()
+        if name == "cholesky_ok":
+            assert val == "1", line
+        else:
+            assert float(val) < 1e-12, line
+        seen += 1
+    assert seen == 21
