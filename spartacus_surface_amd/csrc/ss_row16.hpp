@@ -20,9 +20,10 @@
 // inline asm, so every asm block opens with s_nop 1; the blocks are volatile: they keep their
 // program order and are never sunk into divergent control flow (a DPP read of a lane that EXEC
 // has switched off does not happen: all 16 lanes of a row always take the same branches).
-// They also clobber "memory": loads and stores stay where they are written relative to the
-// arithmetic (the scheduler otherwise hoists every load of a kernel to its top, and the matrices
-// they fetch then sit in registers - or in spill slots - until their turn comes).
+// (A "memory" clobber on them, which pins loads and stores between the blocks, was needed while the
+// record addresses cost dozens of registers - ss_layer16.hpp, "Addresses" - and is off since:
+// -DSS_R16_MEMCLOBBER; without it the longwave downward passes overlap their loads with the
+// arithmetic, 0.62 -> 0.44 ms.)
 //
 // Host builds (tests/emul, TEST-ONLY) run the same code on a pack of 16 doubles.
 #pragma once
@@ -76,6 +77,11 @@ SS_HD void each(const rv& x, F&& f) { f(lane(), x); }
 SS_HD double uniform(rv x) { return x; }
 
 #define SS_R16_DPP " row_mask:0xf bank_mask:0xf\n"
+#if defined(SS_R16_MEMCLOBBER)      // experiment: pin loads and stores between the asm blocks
+#define SS_R16_CLOBBER : "memory"
+#else
+#define SS_R16_CLOBBER
+#endif
 // value of lane K of the row, on every lane
 template <int K>
 SS_HD double bc(rv x) {
@@ -87,28 +93,28 @@ SS_HD double bc(rv x) {
 #define SS_R16_L(o, i) "v_fmac_f64_dpp %" #o ", %" #i ", %[a] row_newbcast:%[k]" SS_R16_DPP
 template <int K>
 SS_HD void fma1(rv& c0, rv b0, rv a) {
-  asm volatile("s_nop 1\n" SS_R16_L(0, 1) : "+v"(c0) : "v"(b0), [a] "v"(a), [k] "n"(K) : "memory");
+  asm volatile("s_nop 1\n" SS_R16_L(0, 1) : "+v"(c0) : "v"(b0), [a] "v"(a), [k] "n"(K) SS_R16_CLOBBER);
 }
 template <int K>
 SS_HD void fma2(rv& c0, rv& c1, rv b0, rv b1, rv a) {
-  asm volatile("s_nop 1\n" SS_R16_L(0, 2) SS_R16_L(1, 3) : "+v"(c0), "+v"(c1) : "v"(b0), "v"(b1), [a] "v"(a), [k] "n"(K) : "memory");
+  asm volatile("s_nop 1\n" SS_R16_L(0, 2) SS_R16_L(1, 3) : "+v"(c0), "+v"(c1) : "v"(b0), "v"(b1), [a] "v"(a), [k] "n"(K) SS_R16_CLOBBER);
 }
 template <int K>
 SS_HD void fma3(rv* c, const rv* b, rv a) {
   asm volatile("s_nop 1\n" SS_R16_L(0, 3) SS_R16_L(1, 4) SS_R16_L(2, 5)
-               : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]) : "v"(b[0]), "v"(b[1]), "v"(b[2]), [a] "v"(a), [k] "n"(K) : "memory");
+               : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]) : "v"(b[0]), "v"(b[1]), "v"(b[2]), [a] "v"(a), [k] "n"(K) SS_R16_CLOBBER);
 }
 template <int K>
 SS_HD void fma4(rv* c, const rv* b, rv a) {
   asm volatile("s_nop 1\n" SS_R16_L(0, 4) SS_R16_L(1, 5) SS_R16_L(2, 6) SS_R16_L(3, 7)
                : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
-               : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), [a] "v"(a), [k] "n"(K) : "memory");
+               : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), [a] "v"(a), [k] "n"(K) SS_R16_CLOBBER);
 }
 template <int K>
 SS_HD void fma6(rv* c, const rv* b, rv a) {
   asm volatile("s_nop 1\n" SS_R16_L(0, 6) SS_R16_L(1, 7) SS_R16_L(2, 8) SS_R16_L(3, 9) SS_R16_L(4, 10) SS_R16_L(5, 11)
                : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5])
-               : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), [a] "v"(a), [k] "n"(K) : "memory");
+               : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), [a] "v"(a), [k] "n"(K) SS_R16_CLOBBER);
 }
 template <int K>
 SS_HD void fma12(rv* c, const rv* b, rv a) {
@@ -118,7 +124,7 @@ SS_HD void fma12(rv* c, const rv* b, rv a) {
                : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]),
                  "+v"(c[8]), "+v"(c[9]), "+v"(c[10]), "+v"(c[11])
                : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]), "v"(b[8]),
-                 "v"(b[9]), "v"(b[10]), "v"(b[11]), [a] "v"(a), [k] "n"(K) : "memory");
+                 "v"(b[9]), "v"(b[10]), "v"(b[11]), [a] "v"(a), [k] "n"(K) SS_R16_CLOBBER);
 }
 #undef SS_R16_L
 // c[j] += bcast_K(b[j]) * a for j = J0 .. M-1, in as few asm blocks as the operand limit allows
