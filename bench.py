@@ -168,14 +168,16 @@ def parity_of_sample(case, ref_out, kind, ntruth=2048):
 
 
 def pmc_summary(workload):
-    """The committed PMC summary of the headline workload (profiles/traffic.json, written by
+    """The committed PMC summary of the workload (profiles/traffic.json for the headline one,
+    profiles/traffic_c3ns4.json for C3 with 4 streams; written by
     tools/pmc_to_profile.py from separate rocprofv3 --pmc passes; FETCH_SIZE doubled per
     MI355X_MICROARCH.md): bytes moved between L2 and the fabric and executed fp64 flops,
     per column and kernel family."""
-    if workload != "c3":
+    name = {"c3": "traffic.json", "c3ns4": "traffic_c3ns4.json"}.get(workload)
+    if name is None:
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             t = json.load(f)
         t["bytes_per_column"], t["fp64_flops_per_column_executed"]     # noqa: B018
         return t

@@ -91,6 +91,13 @@ for k, c in sorted(agg.items()):
     t["fetch_x2"] += 2 * fetch / ncol
     t["write"] += write / ncol
     t["flops"] += d["derived"].get("fp64_flops_per_column_executed", 0.0)
+# kernels that serve both spectral regions in launches of their own (k_pre16, k_eig_coop): half to each layer family
+if "layer_both" in traffic:
+    both = traffic.pop("layer_both")
+    for fam in ("sw_layer", "lw_layer"):
+        t = traffic.setdefault(fam, {"fetch_x2": 0.0, "write": 0.0, "flops": 0.0})
+        for k in both:
+            t[k] += 0.5 * both[k]
 json.dump(out, open("profiles/%s_pmc.json" % tag, "w"), indent=1)
 json.dump({"source": "profiles/%s_pmc.json" % tag, "workload": "%s, %d columns" % (workload, ncol),
            "note": "HBM bytes per column per kernel family from FETCH_SIZE (x2, gfx950 correction of "
