@@ -101,6 +101,43 @@ def c2_rami4pilps(ncol=100_000):
                    top_flux_dn_direct_sw=np.ones((ncol, 1)))
 
 
+def rami5_replicated(ncol=20_000, scene="HET09_JBS_SUM-41-direct"):
+    """BASELINE config 5 as a throughput workload: one column of the reference's test/rami5 run
+    `scene` (its inputs as stored in tests/golden/rami5__<scene>.npz by tests/golden/make_golden.py:
+    vegetated tile with 3 regions x 4 streams - 12 x 12 matrices -, 40-62 layers, 14 shortwave bands,
+    no longwave) replicated `ncol` times."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden",
+                        "rami5__%s.npz" % scene)
+    z = np.load(path)
+    meta = json.loads(bytes(z["meta"]).decode())
+    meta.pop("do_simple_spectrum")
+    meta.pop("want_profiles")
+    cfg = Config(**meta)
+    cfg.consolidate()
+    nlay0 = int(np.array(z["canopy.nlay"])[0])
+    assert np.array(z["canopy.nlay"]).size == 1
+    cp = CanopyProperties().set_layers(np.full(ncol, nlay0, dtype=np.int32))
+    sw = SwSpectralProperties(nspec=cfg.nsw)
+    lw = LwSpectralProperties(nspec=cfg.nlw)
+    extra = {}
+    for k in z.files:
+        for prefix, obj in (("canopy.", cp), ("sw.", sw), ("lw.", lw), ("driver.", None)):
+            if not k.startswith(prefix):
+                continue
+            name, a = k[len(prefix):], np.array(z[k])
+            if name in ("nlay", "istartlay"):
+                continue
+            if a.ndim >= 1 and a.shape[0] in (1, nlay0):
+                a = np.tile(a, (ncol,) + (1,) * (a.ndim - 1))
+            if obj is None:
+                extra[name] = a
+            else:
+                setattr(obj, name, a)
+    return _finish(cfg, cp, sw, lw, **extra)
+
+
 def _urban_columns(rng, ncol, nsw, nlw):
     """ncol jittered Russell-Square columns (10 layers): canopy + SW + LW arrays."""
     base = russell_square_10_layers()
