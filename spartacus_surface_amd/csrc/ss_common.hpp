@@ -228,4 +228,31 @@ SS_HD double ss_sign(double a, double b) { return copysign(fabs(a), b); }
 SS_HD double ss_max(double a, double b) { return a > b ? a : b; }   // Fortran max
 SS_HD double ss_min(double a, double b) { return a < b ? a : b; }
 
+// 1 / x and sqrt(x), 1 / sqrt(x) from the hardware estimates and two Newton / Goldschmidt steps
+// (relative error of a few 1e-16, no denormal or division-by-zero fix-up).  For the kernels of the
+// orders 7..16: rotation angles of the Jacobi kernel (a rotation built from cs = 1 / sqrt(1 + t^2),
+// sn = cs t is orthogonal to rounding whatever the error of t), reciprocal pivots of the unpivoted LU and
+// of the symmetric elimination (ss_row16.hpp, ss_layer16.hpp) - an IEEE division is 12 instructions, a
+// square root plus a division 40.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(r, fma(-x, r, 1.0), r);
+  return fma(r, fma(-x, r, 1.0), r);
+}
+__device__ __forceinline__ void fast_sqrt_rsqrt(double x, double& s, double& rs) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double e = fma(-h, g, 0.5);
+  g = fma(g, e, g);
+  h = fma(h, e, h);
+  e = fma(-h, g, 0.5);
+  s = fma(g, e, g);
+  rs = 2.0 * fma(h, e, h);
+}
+#else
+inline double fast_rcp(double x) { return 1.0 / x; }
+inline void fast_sqrt_rsqrt(double x, double& s, double& rs) { s = std::sqrt(x); rs = 1.0 / s; }
+#endif
+
 }  // namespace ss

@@ -261,28 +261,6 @@ __device__ __forceinline__ double group_sum(double x) {
   for (int m = 1; m < G; m <<= 1) x += __shfl_xor(x, m);
   return x;
 }
-// 1 / x and sqrt(x), 1 / sqrt(x) from the hardware estimates and two Newton / Goldschmidt steps
-// (relative error of a few 1e-16, no denormal or division-by-zero fix-up: the arguments here are sums of
-// squares of a positive definite problem).  A rotation built from them is orthogonal to rounding
-// whatever the error of its angle, which only costs convergence speed.
-__device__ __forceinline__ double fast_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(r, fma(-x, r, 1.0), r);
-  return fma(r, fma(-x, r, 1.0), r);
-}
-__device__ __forceinline__ void fast_sqrt_rsqrt(double x, double& s, double& rs) {
-  const double y = __builtin_amdgcn_rsq(x);
-  double g = x * y, h = 0.5 * y;
-  double e = fma(-h, g, 0.5);
-  g = fma(g, e, g);
-  h = fma(h, e, h);
-  e = fma(-h, g, 0.5);
-  s = fma(g, e, g);
-  rs = 2.0 * fma(h, e, h);
-}
-#else
-inline double fast_rcp(double x) { return 1.0 / x; }
-inline void fast_sqrt_rsqrt(double x, double& s, double& rs) { s = std::sqrt(x); rs = 1.0 / s; }
 #endif
 
 // One group of G lanes = one problem; "q" = lane within the group; rows q, q + G, ... of W and Y.

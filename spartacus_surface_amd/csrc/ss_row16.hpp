@@ -267,7 +267,7 @@ SS_HD void lu_factor(LU<N>& f) {
   f.rdd = 0.0;
   static_for<0, N>([&](auto kc) {
     constexpr int K = decltype(kc)::value;
-    const double rp = 1.0 / bc<K>(f.a[K]);
+    const double rp = 1.0 / bc<K>(f.a[K]);      // (fast_rcp here: no measurable gain, kept IEEE)
     f.rdd = select(lane_eq(K), rv(rp), f.rdd);
     const rv s = f.a[K] * rp;                       // rows above: u_ik / u_kk (final), rows below: l_ik
     const rv l = select(lane_gt(K), s, rv(0.0));
