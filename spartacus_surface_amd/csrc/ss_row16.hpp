@@ -25,7 +25,8 @@
 // -DSS_R16_MEMCLOBBER; without it the longwave downward passes overlap their loads with the
 // arithmetic, 0.62 -> 0.44 ms.)
 //
-// Host builds (tests/emul, TEST-ONLY) run the same code on a pack of 16 doubles.
+// Host builds (tests/emul, TEST-ONLY) run the same code on a pack of 16 doubles, which they bring
+// along themselves (tests/emul/row16_pack.hpp through -DSS_ROW16_PACK_HEADER).
 #pragma once
 
 #include <type_traits>
@@ -150,51 +151,43 @@ SS_HD void row_fma_from(rv* c, const rv* b, rv a) {
   }
 }
 
-#else
-// ------------------------------------------------------------------ host: a pack of 16 lanes
-struct rv {
-  double v[kRow];
-  rv() = default;
-  rv(double x) { for (int l = 0; l < kRow; ++l) v[l] = x; }
-};
-struct rm { bool v[kRow]; };
-#define SS_R16_OP(op)                                                                                   \
-  inline rv operator op(const rv& a, const rv& b) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = a.v[l] op b.v[l]; return r; } \
-  inline rv operator op(const rv& a, double b) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = a.v[l] op b; return r; }       \
-  inline rv operator op(double a, const rv& b) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = a op b.v[l]; return r; }
-SS_R16_OP(+) SS_R16_OP(-) SS_R16_OP(*) SS_R16_OP(/)
-#undef SS_R16_OP
-inline rv operator-(const rv& a) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = -a.v[l]; return r; }
-inline rv& operator*=(rv& a, const rv& b) { a = a * b; return a; }
-inline rv& operator*=(rv& a, double b) { a = a * b; return a; }
-inline rv& operator+=(rv& a, const rv& b) { a = a + b; return a; }
-inline rv& operator-=(rv& a, const rv& b) { a = a - b; return a; }
-inline rm lane_lt(int k) { rm m; for (int l = 0; l < kRow; ++l) m.v[l] = l < k; return m; }
-inline rm lane_gt(int k) { rm m; for (int l = 0; l < kRow; ++l) m.v[l] = l > k; return m; }
-inline rm lane_eq(int k) { rm m; for (int l = 0; l < kRow; ++l) m.v[l] = l == k; return m; }
-inline rv select(const rm& m, const rv& a, const rv& b) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = m.v[l] ? a.v[l] : b.v[l]; return r; }
-inline rv r_sqrt(const rv& x) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = std::sqrt(x.v[l]); return r; }
-inline rv r_exp(const rv& x) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = std::exp(x.v[l]); return r; }
-inline rv r_max(const rv& a, double b) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = a.v[l] > b ? a.v[l] : b; return r; }
-inline rv r_max(const rv& a, const rv& b) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = a.v[l] > b.v[l] ? a.v[l] : b.v[l]; return r; }
-inline rv r_abs(const rv& x) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = std::fabs(x.v[l]); return r; }
+#elif defined(__HIPCC__)
+// ------------------------------------------------------------------ host pass of hipcc: the same
+// one-value-per-lane types so that the __host__ __device__ kernel bodies parse; never executed (the
+// product launches them as kernels only, and there is no CPU fallback)
+using rv = double;
+using rm = bool;
+SS_HD int lane() { return 0; }
+SS_HD rm lane_lt(int k) { return 0 < k; }
+SS_HD rm lane_gt(int) { return false; }
+SS_HD rm lane_eq(int k) { return 0 == k; }
+SS_HD rv select(rm m, rv a, rv b) { return m ? a : b; }
+SS_HD rv r_sqrt(rv x) { return sqrt(x); }
+SS_HD rv r_exp(rv x) { return exp(x); }
+SS_HD rv r_max(rv a, double b) { return a > b ? a : b; }
+SS_HD rv r_abs(rv x) { return fabs(x); }
 template <class F>
-inline rv gen(F&& f) { rv r; for (int l = 0; l < kRow; ++l) r.v[l] = f(l); return r; }
+SS_HD rv gen(F&& f) { return f(0); }
 template <class F>
-inline rm gen_mask(F&& f) { rm m; for (int l = 0; l < kRow; ++l) m.v[l] = f(l); return m; }
-inline bool lane0() { return true; }
+SS_HD rm gen_mask(F&& f) { return f(0); }
+SS_HD bool lane0() { return true; }
 template <class F>
-inline void each(const rv& x, F&& f) { for (int l = 0; l < kRow; ++l) f(l, x.v[l]); }
-inline double uniform(const rv& x) { return x.v[0]; }
+SS_HD void each(const rv& x, F&& f) { f(0, x); }
+SS_HD double uniform(rv x) { return x; }
 template <int K>
-inline double bc(const rv& x) { return x.v[K]; }
+SS_HD double bc(rv x) { return x; }
 template <int K, int J0, int M>
-inline void row_fma_from(rv* c, const rv* b, const rv& a) {
-  for (int j = J0; j < M; ++j) {
-    const double s = b[j].v[K];
-    for (int l = 0; l < kRow; ++l) c[j].v[l] = std::fma(s, a.v[l], c[j].v[l]);
-  }
+SS_HD void row_fma_from(rv* c, const rv* b, rv a) {
+  for (int j = J0; j < M; ++j) c[j] += b[j] * a;
 }
+#elif defined(SS_ROW16_PACK_HEADER)
+}  // namespace r16
+}  // namespace ss
+#include SS_ROW16_PACK_HEADER      // TEST-ONLY host emulation (tests/emul/row16_pack.hpp): rv = a pack of 16 doubles
+namespace ss {
+namespace r16 {
+#else
+#error "ss_row16.hpp is device code (hipcc); host builds of the test-suite supply the lane pack with -DSS_ROW16_PACK_HEADER"
 #endif
 
 template <int K, int M>

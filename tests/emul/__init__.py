@@ -7,13 +7,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libss_emul.so")
 _lib = None
 
-CXXFLAGS = ["-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas"]
+CXXFLAGS = ["-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+            # the "lane" type of the row-of-16 kernels for host builds (a pack of 16 doubles): TEST-ONLY
+            "-I", HERE, '-DSS_ROW16_PACK_HEADER="row16_pack.hpp"']
 
 
 def build(force=False, extra_flags=()):
     src = os.path.join(HERE, "ss_emul.cpp")
     csrc = os.path.join(HERE, "..", "..", "spartacus_surface_amd", "csrc")
-    deps = [src] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
+    deps = [src, os.path.join(HERE, "row16_pack.hpp")] + [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hpp")]
     if (not force and os.path.exists(LIB)
             and os.path.getmtime(LIB) >= max(os.path.getmtime(d) for d in deps)):
         return LIB

@@ -39,7 +39,8 @@ def test_row16_primitives_on_lane_packs(tmp_path):
     'lanes' against plain loops (tests/emul/row16_check.cpp; the device runs the same source with
     v_fmac_f64_dpp row_newbcast as the broadcast-multiply-add)."""
     exe = str(tmp_path / "row16_check")
-    subprocess.run(["g++", "-O1", "-std=c++17", "-Wno-unknown-pragmas", "-o", exe,
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wno-unknown-pragmas", "-I", os.path.join(HERE, "emul"),
+                    '-DSS_ROW16_PACK_HEADER="row16_pack.hpp"', "-o", exe,
                     os.path.join(HERE, "emul", "row16_check.cpp")], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     seen = 0
