@@ -120,7 +120,10 @@ SS_HD bool cholesky_rows(rv* A, rv* Lr, double* rs, double thr) {
 // The factors the cooperative Jacobi kernel and the layer kernel need (what coop_eig_pre does on one
 // lane): with C = -D^-1 (G1 - G2) D = L L^T and M = C - 2 D^-1 G2 D = F F^T: W = F^T L, D L, -D L^-T.
 // In: G1, G2 and dscale as the first pass of the layer kernel left them.  A unit whose matrices are not positive definite gets status 0 (second pass, general solver).
-template <int N>
+// Longwave: also inv_gamma_b = -(G1 + G2)^-1 b (lw_eig :178-195), in place of b: G1 + G2 = -D M D^-1, so it
+// is D F^-T F^-1 D^-1 b - two substitutions with the factor that is at hand here, where the layer kernel
+// used to factorise G1 + G2.
+template <int N, bool LW>
 SS_HD void eig_pre(double* erec, long stride, unsigned long long* one_lane_units) {
   using ER = EigRec<N>;
   const rv dsc = load_vec<N>(erec, stride, ER::VEC);
@@ -171,6 +174,20 @@ SS_HD void eig_pre(double* erec, long stride, unsigned long long* one_lane_units
     rv FT[N], W[N];
     SS_UNROLL_FULL
     for (int k = 0; k < N; ++k) FT[k] = select(lane_gt(k), rv(0.0), M[k] * rsF_own);
+    if (LW) {
+      // F y = D^-1 b downward, F^T z = y upward (row k is used unscaled: x_k = (row k) / F_kk), igb = D z
+      rv v = load_vec<N>(erec, stride, ER::VEC + N) * rd;
+      static_for<0, N - 1>([&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        fma_bc<K>(v, v, select(lane_gt(K), -(F[K] * rsF[K]), rv(0.0)));
+      });
+      v = v * rsF_own;
+      static_for_down<1, N>([&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        fma_bc<K>(v, v, select(lane_lt(K), -(FT[K] * rsF[K]), rv(0.0)));
+      });
+      store_vec<N>(erec, stride, ER::VEC + N, (v * rsF_own) * dsc);
+    }
     mul<N, N, false, false>(FT, nullptr, L, W);
     SS_UNROLL_FULL
     for (int j = 0; j < N; ++j)
@@ -290,20 +307,8 @@ SS_HD void layer_lw(const double* erec, long stride, double* lrec) {
   using ER = EigRec<N>;
   using LR = LwRec<N>;
   const double dz = rec_elem_load(erec, stride, 1);
-  // inv_gamma_b = -(G1 + G2)^-1 b (lw_eig :178-195 through the identity of ss_layer_matrices.hpp)
-  rv igb;
-  {
-    LU<N> B;
-    rv g2[N];
-    load_rowmajor<N, N>(erec, stride, ER::G1, B.a);
-    load_rowmajor<N, N>(erec, stride, ER::G2, g2);
-    SS_UNROLL_FULL
-    for (int j = 0; j < N; ++j) B.a[j] = B.a[j] + g2[j];
-    lu_factor<N>(B);
-    rv v[1] = {-load_vec<N>(erec, stride, ER::VEC + N)};
-    lu_solve<N, 1>(B, v);
-    igb = v[0];
-  }
+  // inv_gamma_b = -(G1 + G2)^-1 b (lw_eig :178-195): left in the record by eig_pre
+  const rv igb = load_vec<N>(erec, stride, ER::VEC + N);
   Diffuse<N> df;
   {
     rv X[N], AX[N];

@@ -210,7 +210,7 @@ __global__ void __launch_bounds__(64, 2) k_unit_row16(const UnitArgs A) {
   if constexpr (ss::coop_order(N)) {
     double* erec = A.eig + ss::rec_base(0, 1, ss::EigRec<N>::NELEM, m);
     if (!(ss::rec_elem_load(erec, ss::kRecStride, ss::EigRec<N>::STATUS) > 0.5)) return;
-    if constexpr (STEP == 0) ss::r16::eig_pre<N>(erec, ss::kRecStride, nullptr);
+    if constexpr (STEP == 0) ss::r16::eig_pre<N, LW>(erec, ss::kRecStride, nullptr);
     else if constexpr (LW) ss::r16::layer_lw<N>(erec, ss::kRecStride, A.rec + ss::rec_base(0, 1, ss::LwRec<N>::NELEM, m));
     else ss::r16::layer_sw<N, D>(erec, ss::kRecStride, A.rec + ss::rec_base(0, 1, ss::SwRec<N, D>::NELEM, m));
   }

@@ -45,6 +45,8 @@ def family_of(kernel, args):
     a = [x.strip() for x in args.split(",")]
     if kernel == "k_layer16":
         return "lw_layer" if a[2] == "true" else "sw_layer"
+    if kernel == "k_pre16" and len(a) > 1:          # k_pre16<N, LW>
+        return "lw_layer" if a[1] == "true" else "sw_layer"
     if kernel in ("k_pre16", "k_eig_coop"):
         return "layer_both"
     kernel = {"k_column16": "k_column", "k_down16": "k_down"}.get(kernel, kernel)
