@@ -17,35 +17,6 @@
 namespace ss {
 namespace r16 {
 
-// what a lane knows about its row i = (region, stream)
-template <int NREG, int NS>
-struct RowGeom {
-  rm sm[NS];       // stream of the own row is s (rows beyond the order: never)
-  rm rg[NREG];     // region of the own row is r
-  rv hw;           // hweight of the own stream
-  SS_HD explicit RowGeom(const LG& lg) {
-    constexpr int N = NREG * NS;
-    SS_UNROLL_FULL
-    for (int s = 0; s < NS; ++s) sm[s] = gen_mask([=](int i) { return i < N && (i % NS) == s; });
-    SS_UNROLL_FULL
-    for (int r = 0; r < NREG; ++r) rg[r] = gen_mask([=](int i) { return i < N && (i / NS) == r; });
-    hw = 0.0;
-    SS_UNROLL_FULL
-    for (int s = 0; s < NS; ++s) hw = select(sm[s], rv(lg.hweight[s]), hw);
-  }
-  // own row of an NREG-row matrix given on every lane (column-major, NREG rows, NC columns)
-  template <int NC>
-  SS_HD void own_row(const double* U, rv* urow) const {
-    SS_UNROLL_FULL
-    for (int c = 0; c < NC; ++c) {
-      rv u = 0.0;
-      SS_UNROLL_FULL
-      for (int r = 0; r < NREG; ++r) u = select(rg[r], rv(SS_E(U, r, c, NREG)), u);
-      urow[c] = u;
-    }
-  }
-};
-
 // A (N x M) = (U (x) I) B for the canopy rows of B (N x M): urow = own row of U
 template <int NREG, int NS, int M>
 SS_HD void apply_U(const RowGeom<NREG, NS>& g, const rv* urow, const rv* B, rv* A) {

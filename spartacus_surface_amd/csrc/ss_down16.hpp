@@ -327,46 +327,34 @@ SS_HD void sw_int_flux_rows(const Launch& L, const RowGeom<NREG, NS>& g, const L
   }
   double ext_reg[NREG], ssa_reg[NREG];
   region_optics<NREG>(air_ext, air_ssa, geo.veg_ext, veg_ssa, od, ext_reg, ssa_reg);
-  // what the own row (region ri, stream si) needs
-  rv tan_i = 0.0, w_i = 0.0, vw_i = 0.0, mu_i = 1.0, ext_i = 0.0, ssa_i = 0.0, fw_i = 0.0;
+  // own rows of the exchange / extinction part and of Gamma2, own non-zero element of Gamma3
+  GammaScalars<NREG> q;
   SS_UNROLL_FULL
-  for (int s = 0; s < NS; ++s) {
-    tan_i = select(g.sm[s], rv(lg.tan_ang[s]), tan_i);
-    w_i = select(g.sm[s], rv(lg.weight[s]), w_i);
-    vw_i = select(g.sm[s], rv(lg.vweight[s]), vw_i);
-    mu_i = select(g.sm[s], rv(lg.mu[s]), mu_i);
-  }
-  rv fxrow[NREG], fxcol[NREG];
+  for (int r = 0; r < NREG; ++r) { q.ext[r] = ext_reg[r]; q.ssa[r] = ssa_reg[r]; q.fw[r] = f_wall[r]; }
   SS_UNROLL_FULL
-  for (int r = 0; r < NREG; ++r) {
-    ext_i = select(g.rg[r], rv(ext_reg[r]), ext_i);
-    ssa_i = select(g.rg[r], rv(ssa_reg[r]), ssa_i);
-    fw_i = select(g.rg[r], rv(f_wall[r]), fw_i);
-  }
-  SS_UNROLL_FULL
-  for (int q = 0; q < NREG; ++q) {
-    rv a = 0.0, b = 0.0;
+  for (int k = 0; k < NREG * NREG; ++k) q.fx[k] = fx[k];
+  q.wall_ext = wall_ext;
+  q.wall_factor = wall_factor;
+  rv E[N], G2[N];
+  gamma_rows<URBAN, NREG, NS, false>(lg, g, q, E, G2);
+  {
+    rv w_i = 0.0, vw_i = 0.0, es_i = 0.0, fw_i = 0.0;
+    SS_UNROLL_FULL
+    for (int s = 0; s < NS; ++s) {
+      w_i = select(g.sm[s], rv(lg.weight[s]), w_i);
+      vw_i = select(g.sm[s], rv(lg.vweight[s]), vw_i);
+    }
+    rv ext_i = 0.0, ssa_i = 0.0;
     SS_UNROLL_FULL
     for (int r = 0; r < NREG; ++r) {
-      a = select(g.rg[r], rv(SS_E(fx, r, q, NREG)), a);     // fx(jto = own, jfr = q)
-      b = select(g.rg[r], rv(SS_E(fx, q, r, NREG)), b);     // fx(jto = q, jfr = own)
+      ext_i = select(g.rg[r], rv(ext_reg[r]), ext_i);
+      ssa_i = select(g.rg[r], rv(ssa_reg[r]), ssa_i);
+      fw_i = select(g.rg[r], rv(f_wall[r]), fw_i);
     }
-    fxrow[q] = a;
-    fxcol[q] = b;
+    (void)es_i;
+    if (URBAN) g3own = 0.5 * (w_i * ext_i * ssa_i + vw_i * sin0 * fw_i * wall_factor);
+    else g3own = 0.5 * w_i * ext_i * ssa_i;
   }
-  rv diag = 0.0;
-  SS_UNROLL_FULL
-  for (int q = 0; q < NREG; ++q) diag = select(g.rg[q], diag, diag - tan_i * fxcol[q]);
-  if (URBAN) diag = diag - ext_i / mu_i - tan_i * fw_i * wall_ext;
-  else diag = diag - ext_i / mu_i;
-  rv g2s[NS];
-  SS_UNROLL_FULL
-  for (int sj = 0; sj < NS; ++sj) {
-    if (URBAN) g2s[sj] = 0.5 * (w_i * ext_i * ssa_i / lg.mu[sj] + vw_i * lg.tan_ang[sj] * fw_i * wall_factor);
-    else g2s[sj] = 0.5 * w_i * ext_i * ssa_i / lg.mu[sj];
-  }
-  if (URBAN) g3own = 0.5 * (w_i * ext_i * ssa_i + vw_i * sin0 * fw_i * wall_factor);
-  else g3own = 0.5 * w_i * ext_i * ssa_i;
   // the sub-problem of this layer (the 3-way branch of layer_unit_sw)
   const bool clear_only = (NREG == 1) || (geo.veg_fraction <= L.cfg.min_vegetation_fraction);
   const bool veg_only = !clear_only && (frac[0] <= L.cfg.min_vegetation_fraction);
@@ -375,11 +363,9 @@ SS_HD void sw_int_flux_rows(const Launch& L, const RowGeom<NREG, NS>& g, const L
   for (int r = 0; r < NREG; ++r) inc_r[r] = clear_only ? (r == 0) : (veg_only ? (r >= 1) : true);
   SS_UNROLL_FULL
   for (int j = 0; j < N; ++j) {
-    const int rj = j / NS, sj = j % NS;
-    rv v = select(g.sm[sj], select(g.rg[rj], rv(0.0), tan_i * fxrow[rj]), rv(0.0));
-    v = select(lane_eq(j), diag, v);
+    const int rj = j / NS;
     // Gamma1 (as used) = exchange / extinction part + Gamma2, so Gamma1 + Gamma2 adds it twice
-    v = select(g.rg[rj], (v + g2s[sj]) + g2s[sj], v);
+    const rv v = (E[j] + G2[j]) + G2[j];
     const rv ident = select(lane_eq(j), rv(1.0), rv(0.0));
     B[j] = inc_r[rj] ? select(inc_i, v, ident) : ident;
   }

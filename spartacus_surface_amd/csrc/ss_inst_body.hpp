@@ -92,8 +92,9 @@ constexpr int kParts16 = kBlock / kUnits16;         // workgroups per tile of 64
 
 // Cholesky factors of the cooperative units (W, D L, -D L^-T of the eigen record) on the 16 lanes of a
 // DPP row, between the first pass of the layer kernel and the Jacobi kernel; block -> units as k_layer16
-template <int N, bool LW>
+template <bool U, int R, int NS, bool LW>
 __global__ void __launch_bounds__(kBlock16, 2) k_pre16(const Launch L) {
+  constexpr int N = R * NS;
   constexpr int UPB = kUnits16;
   const int part = blockIdx.x % kParts16, tl = blockIdx.x / kParts16;
   const int tile = tl / L.maxlay, jlay = tl % L.maxlay;
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(kBlock16, 2) k_pre16(const Launch L) {
   if constexpr (coop_order(N)) {
     double* erec = L.eig + rec_base(jlay, L.maxlay, EigRec<N>::NELEM, cu);
     if (!(rec_elem_load(erec, kRecStride, EigRec<N>::STATUS) > 0.5)) return;     // same for the whole row
-    r16::eig_pre<N, LW>(erec, kRecStride, L.eigen_fail ? L.eigen_fail + kSlotOneLaneUnits : nullptr);
+    r16::eig_pre_scalars<U, R, NS, LW>(L.lg, erec, kRecStride, L.eigen_fail ? L.eigen_fail + kSlotOneLaneUnits : nullptr);
   }
 }
 
@@ -208,7 +209,7 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev, hipStream_t f
                        stream, L);
     SS_TRY(hipGetLastError());
     if constexpr (r16_layer(SS_INST_NREG * NS, SS_INST_LW != 0)) {
-      hipLaunchKernelGGL((k_pre16<SS_INST_NREG * NS, SS_INST_LW != 0>), dim3(gx * (unsigned)L.maxlay * kParts16), dim3(kBlock16), 0, stream, L);
+      hipLaunchKernelGGL((k_pre16<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx * (unsigned)L.maxlay * kParts16), dim3(kBlock16), 0, stream, L);
       SS_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL((k_eig_coop<SS_INST_NREG * NS>), dim3(gx * (unsigned)L.maxlay * coop_lanes(SS_INST_NREG * NS)), dim3(kBlock), 0, stream, L);

@@ -87,6 +87,25 @@ SS_HD void store_colmajor(double* rec, long stride, int off, const rv* A) {
   for (int j = 0; j < M; ++j)
     each(A[j], [&](int i, double x) { if (i < N) rec_elem_store(rec, stride, off + i + j * N, x); });
 }
+// own row of an N x M matrix -> ROW-major block (16-byte pairs along the row where M is even)
+template <int N, int M>
+SS_HD void store_rowmajor(double* rec, long stride, int off, const rv* A) {
+#ifdef SS_R16_FAST_ADDR
+  if constexpr (M % 2 == 0) {
+    const int i = lane();
+    if (i < N) {
+      double* p = rec + (long)(i * M) * stride;
+      SS_PIN(p);
+      SS_UNROLL_FULL
+      for (int j = 0; j < M; j += 2) rec_pair_store(p + (long)(off + j) * stride, A[j], A[j + 1]);
+    }
+    return;
+  }
+#endif
+  SS_UNROLL_FULL
+  for (int j = 0; j < M; ++j)
+    each(A[j], [&](int i, double x) { if (i < N) rec_elem_store(rec, stride, off + i * M + j, x); });
+}
 template <int N>
 SS_HD rv load_vec(const double* rec, long stride, int off) {
   return gen([&](int i) { const int ic = i < N ? i : N - 1; const double v = rec_elem_load(rec, stride, off + ic); return (i < N) ? v : 0.0; });
@@ -94,6 +113,121 @@ SS_HD rv load_vec(const double* rec, long stride, int off) {
 template <int N>
 SS_HD void store_vec(double* rec, long stride, int off, const rv& x) {
   each(x, [&](int i, double v) { if (i < N) rec_elem_store(rec, stride, off + i, v); });
+}
+
+// what a lane knows about its row i = (region, stream)
+template <int NREG, int NS>
+struct RowGeom {
+  rm sm[NS];       // stream of the own row is s (rows beyond the order: never)
+  rm rg[NREG];     // region of the own row is r
+  rv hw;           // hweight of the own stream
+  SS_HD explicit RowGeom(const LG& lg) {
+    constexpr int N = NREG * NS;
+    SS_UNROLL_FULL
+    for (int s = 0; s < NS; ++s) sm[s] = gen_mask([=](int i) { return i < N && (i % NS) == s; });
+    SS_UNROLL_FULL
+    for (int r = 0; r < NREG; ++r) rg[r] = gen_mask([=](int i) { return i < N && (i / NS) == r; });
+    hw = 0.0;
+    SS_UNROLL_FULL
+    for (int s = 0; s < NS; ++s) hw = select(sm[s], rv(lg.hweight[s]), hw);
+  }
+  // own row of an NREG-row matrix given on every lane (column-major, NREG rows, NC columns)
+  template <int NC>
+  SS_HD void own_row(const double* U, rv* urow) const {
+    SS_UNROLL_FULL
+    for (int c = 0; c < NC; ++c) {
+      rv u = 0.0;
+      SS_UNROLL_FULL
+      for (int r = 0; r < NREG; ++r) u = select(rg[r], rv(SS_E(U, r, c, NREG)), u);
+      urow[c] = u;
+    }
+  }
+};
+
+// Scalars of a layer the Gamma matrices are built from, as the first pass of the layer kernel leaves
+// them in the eigen record (slot G1 of the record, which holds no matrix any more)
+template <int NREG>
+struct GammaScalars {
+  static constexpr int EXT = 0, SSA = NREG, FW = 2 * NREG, FX = 3 * NREG, WEXT = 3 * NREG + NREG * NREG,
+                       WFAC = WEXT + 1, COUNT = WFAC + 1;
+  double ext[NREG], ssa[NREG], fw[NREG], fx[NREG * NREG], wall_ext, wall_factor;
+  SS_HD void load(const double* rec, long stride, int off) {
+    SS_UNROLL_FULL
+    for (int r = 0; r < NREG; ++r) {
+      ext[r] = rec_elem_load(rec, stride, off + EXT + r);
+      ssa[r] = rec_elem_load(rec, stride, off + SSA + r);
+      fw[r] = rec_elem_load(rec, stride, off + FW + r);
+    }
+    SS_UNROLL_FULL
+    for (int k = 0; k < NREG * NREG; ++k) fx[k] = rec_elem_load(rec, stride, off + FX + k);
+    wall_ext = rec_elem_load(rec, stride, off + WEXT);
+    wall_factor = rec_elem_load(rec, stride, off + WFAC);
+  }
+  SS_HD void store(double* rec, long stride, int off) const {
+    SS_UNROLL_FULL
+    for (int r = 0; r < NREG; ++r) {
+      rec_elem_store(rec, stride, off + EXT + r, ext[r]);
+      rec_elem_store(rec, stride, off + SSA + r, ssa[r]);
+      rec_elem_store(rec, stride, off + FW + r, fw[r]);
+    }
+    SS_UNROLL_FULL
+    for (int k = 0; k < NREG * NREG; ++k) rec_elem_store(rec, stride, off + FX + k, fx[k]);
+    rec_elem_store(rec, stride, off + WEXT, wall_ext);
+    rec_elem_store(rec, stride, off + WFAC, wall_factor);
+  }
+};
+
+// Own rows of the exchange / extinction part E = Gamma1 - Gamma2 and of Gamma2 (forest :329-376 /
+// urban :383-440 of the longwave solvers, :329-387 / :424-497 of the shortwave ones; the expressions
+// of lw_gamma_elem / sw_gamma_elem, evaluated for the own row).  LWFORM: the association of the forest
+// longwave scattering term, (0.5 w / mu) ext ssa, instead of 0.5 w ext ssa / mu.
+template <bool URBAN, int NREG, int NS, bool LWFORM>
+SS_HD void gamma_rows(const LG& lg, const RowGeom<NREG, NS>& g, const GammaScalars<NREG>& q, rv* E, rv* G2) {
+  constexpr int N = NREG * NS;
+  rv tan_i = 0.0, w_i = 0.0, vw_i = 0.0, mu_i = 1.0, ext_i = 0.0, ssa_i = 0.0, fw_i = 0.0;
+  SS_UNROLL_FULL
+  for (int s = 0; s < NS; ++s) {
+    tan_i = select(g.sm[s], rv(lg.tan_ang[s]), tan_i);
+    w_i = select(g.sm[s], rv(lg.weight[s]), w_i);
+    vw_i = select(g.sm[s], rv(lg.vweight[s]), vw_i);
+    mu_i = select(g.sm[s], rv(lg.mu[s]), mu_i);
+  }
+  SS_UNROLL_FULL
+  for (int r = 0; r < NREG; ++r) {
+    ext_i = select(g.rg[r], rv(q.ext[r]), ext_i);
+    ssa_i = select(g.rg[r], rv(q.ssa[r]), ssa_i);
+    fw_i = select(g.rg[r], rv(q.fw[r]), fw_i);
+  }
+  rv fxrow[NREG], fxcol[NREG];
+  SS_UNROLL_FULL
+  for (int k = 0; k < NREG; ++k) {
+    rv a = 0.0, b = 0.0;
+    SS_UNROLL_FULL
+    for (int r = 0; r < NREG; ++r) {
+      a = select(g.rg[r], rv(SS_E(q.fx, r, k, NREG)), a);     // fx(jto = own, jfr = k)
+      b = select(g.rg[r], rv(SS_E(q.fx, k, r, NREG)), b);     // fx(jto = k, jfr = own)
+    }
+    fxrow[k] = a;
+    fxcol[k] = b;
+  }
+  rv diag = 0.0;
+  SS_UNROLL_FULL
+  for (int k = 0; k < NREG; ++k) diag = select(g.rg[k], diag, diag - tan_i * fxcol[k]);
+  if (URBAN) diag = diag - ext_i / mu_i - tan_i * fw_i * q.wall_ext;
+  else diag = diag - ext_i / mu_i;
+  rv g2s[NS];
+  SS_UNROLL_FULL
+  for (int sj = 0; sj < NS; ++sj) {
+    if (URBAN) g2s[sj] = 0.5 * (w_i * ext_i * ssa_i / lg.mu[sj] + vw_i * lg.tan_ang[sj] * fw_i * q.wall_factor);
+    else if (LWFORM) g2s[sj] = (0.5 * w_i / lg.mu[sj]) * ext_i * ssa_i;
+    else g2s[sj] = 0.5 * w_i * ext_i * ssa_i / lg.mu[sj];
+  }
+  SS_UNROLL_FULL
+  for (int j = 0; j < N; ++j) {
+    const int rj = j / NS, sj = j % NS;
+    E[j] = select(lane_eq(j), diag, select(g.sm[sj], select(g.rg[rj], rv(0.0), tan_i * fxrow[rj]), rv(0.0)));
+    G2[j] = select(g.rg[rj], g2s[sj], rv(0.0));
+  }
 }
 
 // Symmetric elimination of an s.p.d. matrix with its rows on the lanes (both triangles are kept up
@@ -119,12 +253,13 @@ SS_HD bool cholesky_rows(rv* A, rv* Lr, double* rs, double thr) {
 
 // The factors the cooperative Jacobi kernel and the layer kernel need (what coop_eig_pre does on one
 // lane): with C = -D^-1 (G1 - G2) D = L L^T and M = C - 2 D^-1 G2 D = F F^T: W = F^T L, D L, -D L^-T.
-// In: G1, G2 and dscale as the first pass of the layer kernel left them.  A unit whose matrices are not positive definite gets status 0 (second pass, general solver).
+// In: the own rows of G1 - G2 and G2, dscale (and b) from the record.  A unit whose matrices are not positive definite gets status 0 (second pass, general solver).
 // Longwave: also inv_gamma_b = -(G1 + G2)^-1 b (lw_eig :178-195), in place of b: G1 + G2 = -D M D^-1, so it
 // is D F^-T F^-1 D^-1 b - two substitutions with the factor that is at hand here, where the layer kernel
 // used to factorise G1 + G2.
+// (E = own row of G1 - G2, g2 = own row of G2; both are consumed)
 template <int N, bool LW>
-SS_HD void eig_pre(double* erec, long stride, unsigned long long* one_lane_units) {
+SS_HD void eig_pre_rows(double* erec, long stride, const rv* E, const rv* g2, unsigned long long* one_lane_units) {
   using ER = EigRec<N>;
   const rv dsc = load_vec<N>(erec, stride, ER::VEC);
   double d[N];
@@ -133,15 +268,12 @@ SS_HD void eig_pre(double* erec, long stride, unsigned long long* one_lane_units
   rv C[N], M[N];
   double size = 0.0;      // scale of the pivot test: the largest element of the scaled matrices
   {
-    rv g1[N], g2[N];
-    load_rowmajor<N, N>(erec, stride, ER::G1, g1);
-    load_rowmajor<N, N>(erec, stride, ER::G2, g2);
     rv big = 0.0;      // largest |element| of the two scaled matrices in the own row
     SS_UNROLL_FULL
     for (int j = 0; j < N; ++j) {
       const rv sc = rd * d[j];
       const rv sj = g2[j] * sc;
-      C[j] = -((g1[j] - g2[j]) * sc);
+      C[j] = -(E[j] * sc);
       M[j] = C[j] - 2.0 * sj;
       big = r_max(big, r_max(r_abs(C[j]), r_abs(sj)));
     }
@@ -189,13 +321,14 @@ SS_HD void eig_pre(double* erec, long stride, unsigned long long* one_lane_units
       store_vec<N>(erec, stride, ER::VEC + N, (v * rsF_own) * dsc);
     }
     mul<N, N, false, false>(FT, nullptr, L, W);
-    SS_UNROLL_FULL
-    for (int j = 0; j < N; ++j)
-      each(W[j], [&](int i, double x) { if (i < N) rec_elem_store(erec, stride, ER::W + i * N + j, x); });
+    store_rowmajor<N, N>(erec, stride, ER::W, W);
   }
-  SS_UNROLL_FULL
-  for (int j = 0; j < N; ++j)
-    each(L[j] * dsc, [&](int i, double x) { if (i < N) rec_elem_store(erec, stride, ER::X + i * N + j, x); });
+  {
+    rv DL[N];
+    SS_UNROLL_FULL
+    for (int j = 0; j < N; ++j) DL[j] = L[j] * dsc;
+    store_rowmajor<N, N>(erec, stride, ER::X, DL);
+  }
   // -D L^-T: R = L^T is upper triangular with its rows on the lanes; R X = I by back substitution
   {
     rv X[N];
@@ -209,9 +342,33 @@ SS_HD void eig_pre(double* erec, long stride, unsigned long long* one_lane_units
     });
     const rv sc = -(dsc * rsL_own);
     SS_UNROLL_FULL
-    for (int j = 0; j < N; ++j)
-      each(X[j] * sc, [&](int i, double x) { if (i < N) rec_elem_store(erec, stride, ER::AX + i * N + j, x); });
+    for (int j = 0; j < N; ++j) X[j] = X[j] * sc;
+    store_rowmajor<N, N>(erec, stride, ER::AX, X);
   }
+}
+
+// ... from Gamma1, Gamma2 in the record (the kernel-level entries, ss_units_capi.hip)
+template <int N, bool LW>
+SS_HD void eig_pre(double* erec, long stride, unsigned long long* one_lane_units) {
+  using ER = EigRec<N>;
+  rv E[N], g2[N];
+  load_rowmajor<N, N>(erec, stride, ER::G1, E);
+  load_rowmajor<N, N>(erec, stride, ER::G2, g2);
+  SS_UNROLL_FULL
+  for (int j = 0; j < N; ++j) E[j] = E[j] - g2[j];
+  eig_pre_rows<N, LW>(erec, stride, E, g2, one_lane_units);
+}
+// ... from the layer's scalars in the record (the solver: first pass of the layer kernel, layer_first_sw / _lw)
+template <bool URBAN, int NREG, int NS, bool LW>
+SS_HD void eig_pre_scalars(const LG& lg, double* erec, long stride, unsigned long long* one_lane_units) {
+  constexpr int N = NREG * NS;
+  using ER = EigRec<N>;
+  GammaScalars<NREG> q;
+  q.load(erec, stride, ER::G1);
+  const RowGeom<NREG, NS> g(lg);
+  rv E[N], g2[N];
+  gamma_rows<URBAN, NREG, NS, LW>(lg, g, q, E, g2);
+  eig_pre_rows<N, LW>(erec, stride, E, g2, one_lane_units);
 }
 
 // Eigenvectors X = (D L) Y and (G1 - G2)^-1 X = (-D L^-T) Y from the factors and the rotations of the record

@@ -20,7 +20,7 @@
 #include "ss_layer_matrices.hpp"
 #include "ss_eigen_coop.hpp"
 #include "ss_pack.hpp"
-#include "ss_row16.hpp"
+#include "ss_layer16.hpp"
 
 namespace ss {
 
@@ -190,25 +190,17 @@ SS_HD void layer_first_sw(const Launch& L, int cu, int jlay, const W& w) {
       for (int r = 0; r < D; ++r) dsc0[r] = sqrt(p.frac[r]);
       ierr = sw_direct_part<N, D>(g0, dsc0, p.g.dz, w, mu, G0, G0inv, emu);
       rec_elem_store(erec, st, 1, p.g.dz);
+      // the scalars Gamma1 and Gamma2 are built from (r16::gamma_rows builds the rows in k_pre16)
+      r16::GammaScalars<NREG> q;
+      SS_UNROLL_FULL
+      for (int r = 0; r < NREG; ++r) { q.ext[r] = p.ext_reg[r]; q.ssa[r] = p.ssa_reg[r]; q.fw[r] = p.f_wall[r]; }
+      SS_UNROLL_FULL
+      for (int k = 0; k < NREG * NREG; ++k) q.fx[k] = p.fx[k];
+      q.wall_ext = p.wall_ext;
+      q.wall_factor = p.wall_factor;
+      q.store(erec, st, ER::G1);
       r16::static_for<0, N>([&](auto ic) {
         constexpr int I = decltype(ic)::value;
-        r16::static_for<0, (N + 1) / 2>([&](auto jc) {
-          constexpr int J = 2 * decltype(jc)::value;
-          double a1, a2, c1 = 0.0, c2 = 0.0;
-          sw_gamma_elem<URBAN, NREG, NS, I, J>(lg, p, a1, a2);
-          if constexpr (J + 1 < N) sw_gamma_elem<URBAN, NREG, NS, I, J + 1>(lg, p, c1, c2);
-          if constexpr (N % 2 == 0) {
-            rec_pair_store(erec + (long)(ER::G1 + I * N + J) * st, a1, c1);
-            rec_pair_store(erec + (long)(ER::G2 + I * N + J) * st, a2, c2);
-          } else {
-            rec_elem_store(erec, st, ER::G1 + I * N + J, a1);
-            rec_elem_store(erec, st, ER::G2 + I * N + J, a2);
-            if constexpr (J + 1 < N) {
-              rec_elem_store(erec, st, ER::G1 + I * N + J + 1, c1);
-              rec_elem_store(erec, st, ER::G2 + I * N + J + 1, c2);
-            }
-          }
-        });
         rec_elem_store(erec, st, ER::VEC + I, dsc0[I / NS] * lg.sqrt_wmu[I % NS]);
         SS_UNROLL_FULL
         for (int r = 0; r < D; ++r)
