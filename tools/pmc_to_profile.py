@@ -40,13 +40,13 @@ FAMILY = {("k_layer", "false"): "sw_layer", ("k_column", "false"): "sw_column",
 
 def family_of(kernel, args):
     # template arguments: <URBAN, NREG, NS, LW[, STAGE]>; the row-of-16 kernels of the orders 7..16:
-    # k_layer16<N, D, LW>, k_column16 / k_down16 as their one-lane namesakes, k_pre16<N> and
-    # k_eig_coop<N> serve both spectral regions ("layer_both")
+    # k_layer16<N, D, LW>, k_column16 / k_down16 / k_pre16 as the one-lane kernels, k_eig_coop<N> serves
+    # both spectral regions ("layer_both": half to each)
     a = [x.strip() for x in args.split(",")]
     if kernel == "k_layer16":
         return "lw_layer" if a[2] == "true" else "sw_layer"
-    if kernel == "k_pre16" and len(a) > 1:          # k_pre16<N, LW>
-        return "lw_layer" if a[1] == "true" else "sw_layer"
+    if kernel == "k_pre16" and len(a) > 3:          # k_pre16<URBAN, NREG, NS, LW>
+        return "lw_layer" if a[3] == "true" else "sw_layer"
     if kernel in ("k_pre16", "k_eig_coop"):
         return "layer_both"
     kernel = {"k_column16": "k_column", "k_down16": "k_down"}.get(kernel, kernel)
