@@ -30,6 +30,12 @@
 // every matrix element has a compile-time register; larger orders keep rolled
 // loops (arrays then live in scratch memory).
 #define SS_UNROLL_MAX 6
+// Smallest matrix order that runs with one problem on the 16 lanes of a DPP row (ss_row16.hpp).
+// 7 = everything that does not fit the registers of one lane.  -DSS_COOP_MIN_ORDER=6 is the
+// measured experiment "multi-lane cooperative kernels for the headline order" (DESIGN.md section 3).
+#ifndef SS_COOP_MIN_ORDER
+#define SS_COOP_MIN_ORDER (SS_UNROLL_MAX + 1)
+#endif
 #define SS_PRAGMA(x) _Pragma(#x)
 #define SS_UNROLL_N(N) SS_PRAGMA(unroll((N) <= SS_UNROLL_MAX ? (N) : 1))
 #define SS_UNROLL_NN(N) SS_PRAGMA(unroll((N) <= SS_UNROLL_MAX ? (N) * (N) : 1))

@@ -51,7 +51,7 @@ constexpr bool coop_order(int n) {
 #if defined(SS_NO_COOP_EIGEN)
   return false && n > 0;
 #else
-  return n > SS_UNROLL_MAX && n <= kCoopMaxOrder;
+  return n >= SS_COOP_MIN_ORDER && n <= kCoopMaxOrder;
 #endif
 }
 

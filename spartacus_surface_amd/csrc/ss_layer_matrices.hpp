@@ -176,7 +176,7 @@ constexpr bool fused_order(int n, bool lw) {
 #elif defined(SS_FUSE_SW)
   return n <= SS_UNROLL_MAX || (false && lw);
 #else
-  return lw && n <= SS_UNROLL_MAX;
+  return lw && n <= SS_UNROLL_MAX && n < SS_COOP_MIN_ORDER;
 #endif
 }
 
