@@ -125,6 +125,10 @@ struct Cfg {
   double vegetation_isolation_factor;   // of the tile kind (forest / urban)
   int use_symmetric_vegetation_scale;   // of the tile kind
   int do_vegetation;
+  // diagnostic (env SPARTACUS_DECLINE_COOP=1): every full problem of the orders 7..16 is declined by the
+  // cooperative route and takes the second pass of the layer kernel (one lane, general eigen-solver) -
+  // the path of units without the symmetric structure, which well-formed inputs hardly ever reach
+  int decline_cooperative;
 };
 
 // canopy_flux_type members by index (order of radsurf_canopy_flux.F90:27-91,

@@ -704,6 +704,10 @@ class Plan {
     L.cfg.use_symmetric_vegetation_scale = urban ? cfg.use_symmetric_vegetation_scale_urban
                                                  : cfg.use_symmetric_vegetation_scale_forest;
     L.cfg.do_vegetation = cfg.do_vegetation;
+    {
+      const char* e = std::getenv("SPARTACUS_DECLINE_COOP");
+      L.cfg.decline_cooperative = (e && e[0] == '1') ? 1 : 0;
+    }
     L.cols = d_index + c.dev_offset + first;
     L.ncols = (int)count;
     L.nspec = lw ? nlw : nsw;

@@ -94,6 +94,29 @@ def test_golden_host_entry(path):
     assert not bad, "outside the parity bar: %s" % bad[:5]
 
 
+@pytest.mark.parametrize("name", ["urban__4stream", "rami5__HET07_JPS_SUM-56-direct", "rami4pilps__vis-snw-0.3-2-4",
+                                  "extra__urban-5stream"])
+def test_golden_with_cooperative_route_declined(name, monkeypatch):
+    """Orders 7..16: the second pass of the layer kernel (one lane per unit, general eigen-solver, on the
+    plan's fallback stream) is where units without the symmetric structure go; well-formed inputs hardly
+    ever reach it, so SPARTACUS_DECLINE_COOP=1 sends every full problem there.  Same goldens, same bar
+    (the upward and downward sweeps stay on DPP rows)."""
+    radsurf = _hip()
+    have = [p for p in golden_files() if os.path.basename(p)[:-4] == name]
+    if not have:
+        pytest.skip("fixture not present")
+    monkeypatch.setenv("SPARTACUS_DECLINE_COOP", "1")
+    case, expected = fixture_io.load_case(have[0])
+    cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
+    out = _alloc(case)
+    radsurf.radsurf(cfg, cp, sw, lw, out["bc_out"], 1, cp.ncol, out["sw_norm_dir"],
+                    out["sw_norm_diff"], out["lw_internal"], out["lw_norm"])
+    got = fixture_io.flatten_outputs(out)
+    bad = fixture_io.parity_violations(got, expected, dict(case["ref_noise"]), truth=case["ref_truth"],
+                                       noise_arr=case["ref_noise_arr"])
+    assert not bad, "outside the parity bar: %s" % bad[:5]
+
+
 @pytest.mark.parametrize("name", ["simple__test_surfaces", "urban__2stream", "rami4pilps__vis-med-0.3"])
 def test_golden_plan_api_with_device_spectrum(name):
     """ss_plan_*: upload once, calc_simple_spectrum_lw + solve on device,
