@@ -19,16 +19,19 @@
 //    the register-resident orders has to fall back to the general solver for 17 % of its units
 //    (sym_spectrum_is_well_graded); here nothing falls back.
 //  * It only ever combines columns: with the ROWS of W and Y dealt out to the lanes of a group
-//    (row i on lane i mod G) every rotation is lane-local; the three inner products that
-//    define a rotation are a local part plus a butterfly over the G lanes of the group.
-//  * So a 12 x 12 problem lives in the registers of 4 lanes (3 rows of W and of Y each: 144
-//    VGPRs) instead of 17 KB of scratch memory per lane, 16 problems per wave.
-// The kernel (k_eig_coop, ss_inst_body.hpp) sits between two passes of the layer kernel: the
-// first builds W (coop_eig_pre, one lane per problem), the second takes eigenvalues and
-// vectors from the record (coop_eig_post) where the one-kernel form calls the eigen-solver.
+//    (row i on lane i mod G) every rotation is lane-local; the inner product that defines a
+//    rotation is a local part plus a butterfly over the G lanes of the group (the squared column
+//    norms are carried along and recomputed once per sweep).
+//  * So a 12 x 12 problem lives in the registers of 2 lanes (6 rows of W and of Y each)
+//    instead of 17 KB of scratch memory per lane, 32 problems per wave.
+// The kernel (k_eig_coop, ss_inst_body.hpp) sits between the kernels that build W and the factors
+// D L, -D L^-T (k_pre16, r16::eig_pre_scalars in ss_layer16.hpp: Cholesky by symmetric elimination
+// with the matrix rows on the 16 lanes of a DPP row) and the layer kernel that forms X = (D L) Y
+// and the layer matrices from them (k_layer16).  The one-lane forms of the two ends (coop_eig_pre,
+// coop_eig_post) serve builds without the row-of-16 kernels (-DSS_NO_R16_LAYER).
 //
-// Group size G = 4 (a DPP quad).  Orders above 16 (8 streams x 3 regions) keep the one-kernel
-// form: they would need 8 lanes per problem and twice the unrolled code.
+// Group size G: 2 lanes up to order 12, 4 above (coop_lanes).  Orders above 16 (8 streams x 3
+// regions) keep the one-kernel, one-lane form.
 #pragma once
 
 #include "ss_common.hpp"
