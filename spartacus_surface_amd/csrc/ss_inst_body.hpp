@@ -86,7 +86,10 @@ __global__ void __launch_bounds__(kBlock, 1) k_layer_up(const Launch L) {
 // kernels ([element pair][lane][2]: the pairs of 8 neighbouring units make one 128-byte line), and
 // workgroups go to the 8 XCDs round-robin, each with its own L2: with 4 units per workgroup the two
 // halves of every line were fetched (and written) by two different L2s.
-constexpr int kBlock16 = 128;
+#ifndef SS_BLOCK16
+#define SS_BLOCK16 128      // measured on C3 with 4 streams: 64 -> 128 +6 % (whole lines per workgroup), 256 +1.5 %
+#endif
+constexpr int kBlock16 = SS_BLOCK16;
 constexpr int kUnits16 = kBlock16 / r16::kRow;      // units per workgroup
 constexpr int kParts16 = kBlock / kUnits16;         // workgroups per tile of 64 units
 
