@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - canopy columns/s of the SPARTACUS-Surface SW+LW column solver on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c3ns4|c4|rami5] [--scaling weak|strong]
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c3ns4|c4|c4ns4|rami5] [--scaling weak|strong]
 
 A "step" is one pass of the hot path (radsurf: layer kernels + column kernels,
 SW and LW) over one batch of synthetic columns that is already resident in HBM.
@@ -66,6 +66,8 @@ WORKLOAD_NAMES = {
     "c3": "C3: test/urban vegetated-urban SW+LW, 3 regions x 2 streams x 10 layers, 1 SW + 1 LW band",
     "c3ns4": "C3 with 4 streams: vegetated-urban SW+LW, 3 regions x 4 streams x 10 layers (n = 12)",
     "c4": "C4: mixed forest / vegetated-urban SW+LW, 3 regions x 2 streams x 10 layers, 14 SW + 16 LW bands",
+    "c4ns4": "C4 with 4 streams: mixed forest / vegetated-urban SW+LW, 3 regions x 4 streams x 10 layers (n = 12), "
+             "14 SW + 16 LW bands",
     "rami5": "C5: test/rami5 scene HET09_JBS_SUM (41 deg, direct) replicated: vegetated tile, 3 regions x 4 streams "
              "(n = 12) x 62 layers, 14 SW bands, no LW",
 }
@@ -79,6 +81,8 @@ def make_case(workload, ncol, seed):
         return workloads.c3_vegetated_urban(ncol=ncol, seed=seed, nstream=4)
     if workload == "c4":
         return workloads.c4_mixed(ncol=ncol, seed=seed)
+    if workload == "c4ns4":
+        return workloads.c4_mixed(ncol=ncol, seed=seed, nstream=4)
     if workload == "rami5":
         return workloads.rami5_replicated(ncol=ncol)
     return workloads.c3_vegetated_urban(ncol=ncol, seed=seed)
@@ -315,7 +319,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--columns", type=int, default=1_000_000,
                     help="columns per GPU (weak scaling) or in total (strong scaling)")
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3ns4", "c4", "rami5"],
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3ns4", "c4", "c4ns4", "rami5"],
                     help="c3 (default) is the headline configuration; the others are extra lines")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --columns per GPU; strong: --columns in total, sharded over the GPUs "

@@ -208,8 +208,8 @@ def c3_vegetated_urban(ncol=1_000_000, seed=12345, nstream=2):
                    top_flux_dn_lw=np.full((ncol, 1), StefanBoltzmann * t_sky ** 4))
 
 
-def c4_mixed(ncol=1_000_000, seed=12345, nsw=14, nlw=16):
-    """C4: 50/50 forest (10 layers, 3 regions, 2 streams) and C3-like vegetated
+def c4_mixed(ncol=1_000_000, seed=12345, nsw=14, nlw=16, nstream=2):
+    """C4: 50/50 forest (10 layers, 3 regions, `nstream` streams) and C3-like vegetated
     urban columns, 14 SW + 16 LW bands.  SW band values from the rami5 HET09
     table; LW Planck / emission split uniformly over the bands (the reference
     has no LW band model: calc_simple_spectrum_lw aborts for nspec > 1, so the
@@ -217,8 +217,8 @@ def c4_mixed(ncol=1_000_000, seed=12345, nsw=14, nlw=16):
     rng = np.random.default_rng(seed)
     cfg = Config(do_sw=True, do_lw=True, do_vegetation=True, do_urban=True,
                  n_vegetation_region_forest=2, n_vegetation_region_urban=2, nsw=nsw, nlw=nlw,
-                 n_stream_sw_forest=2, n_stream_sw_urban=2, n_stream_lw_forest=2,
-                 n_stream_lw_urban=2).consolidate()
+                 n_stream_sw_forest=nstream, n_stream_sw_urban=nstream, n_stream_lw_forest=nstream,
+                 n_stream_lw_urban=nstream).consolidate()
     L = 10
     base, cpa, alb = _urban_columns(rng, ncol, nsw, nlw)
     is_forest = (np.arange(ncol) % 2 == 0)
