@@ -237,16 +237,25 @@ int spartacus_radsurf_hip(const ss_config *config, const ss_canopy *canopy,
                           ss_flux *sw_norm_dir, ss_flux *sw_norm_diff,
                           ss_flux *lw_internal, ss_flux *lw_norm);
 
-/* Optional page-locking of the caller's arrays for the host entry.  A host model
- * keeps its (allocatable) arrays for the whole run and calls radsurf every time
- * step: locked once, every later copy of them is a direct DMA at PCIe rate that
- * does not block the calling thread, so uploads, kernels and downloads of
- * successive column chunks overlap in both directions.  SPARTACUS_PIN_HOST=1 makes
- * spartacus_radsurf_hip lock every array it is handed (first call pays the
- * locking); ss_host_pin locks one range explicitly.  Nothing is unlocked
- * behind the caller's back: call ss_host_unpin_all before freeing such arrays.
- * Pageable arrays (the default) are always correct, just slower. */
+/* Optional page-locking of the caller's arrays for the host entry: copies of a
+ * locked array are direct DMA at PCIe rate that does not block the calling
+ * thread, so uploads, kernels and downloads of successive column chunks overlap
+ * in both directions.  Pageable arrays (the default) are always correct, just slower.
+ *
+ * ss_host_pin(ptr, bytes): the CALLER owns the lock.  CONTRACT: the range stays
+ * allocated until ss_host_unpin(ptr) / ss_host_unpin_all() - a freed array whose
+ * address the allocator re-uses for new pages makes the next copy a DMA to pages
+ * that are gone: the GPU faults and the runtime ends the process (the library
+ * cannot see a free).  Meant for a host model whose allocatable arrays live for
+ * the whole run: pin once after allocation, unpin before deallocation.  A range
+ * that partly overlaps an existing lock is refused (SS_ERR_HIP).
+ *
+ * SPARTACUS_PIN_HOST=1 (environment): the CALL owns the locks - spartacus_radsurf_hip
+ * locks the slices of [istartcol, iendcol] it is handed on entry and releases
+ * them before it returns (calls below SPARTACUS_PIN_HOST_MIN_COLUMNS, default
+ * 4096, columns are not worth it).  Safe with any allocation pattern. */
 int ss_host_pin(const void *ptr, int64_t bytes);
+int ss_host_unpin(const void *ptr);
 int ss_host_unpin_all(void);
 int ss_host_pinned_bytes(int64_t *bytes);
 

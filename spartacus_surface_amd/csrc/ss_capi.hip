@@ -85,63 +85,81 @@ __global__ void __launch_bounds__(256) k_scale_sum(const ss::ScaleSumLaunch S) {
 
 enum Family { FAM_SW_LAYER = 0, FAM_SW_COLUMN, FAM_LW_LAYER, FAM_LW_COLUMN, FAM_MISC, FAM_SW_DOWN, FAM_LW_DOWN, FAM_COUNT };
 
-// Optional pinning of the caller's arrays (SPARTACUS_PIN_HOST=1 or ss_host_pin): a host model
-// keeps its allocatable arrays for the whole run and calls radsurf every time step, so the
-// arrays can be page-locked ONCE (hipHostRegister); every later copy is then a direct DMA at
-// PCIe rate that does not block the host thread, and uploads, kernels and downloads of
-// successive chunks overlap in both directions.  Pageable arrays (the default) go through the
-// runtime's staging path, which blocks the calling thread per copy.
-// The registry never unpins by itself: ss_host_unpin_all() does (call it before freeing arrays).
+// Page-locked caller arrays (hipHostRegister): copies then move by DMA at PCIe rate without blocking
+// the host thread, so uploads, kernels and downloads of successive chunks overlap in both directions;
+// pageable arrays (the default) go through the runtime's staging path, which blocks per copy.
+//
+// OWNERSHIP - who may keep a registration, and why (round 2 lost a process here).
+// A registration describes an ADDRESS RANGE, and the runtime keeps using it after the memory behind it
+// is gone: when the caller frees an array (munmap for anything above malloc's mmap threshold) and the
+// allocator maps NEW pages at the same address, a copy "through" the stale registration is a DMA to
+// pages that no longer exist - the GPU raises a memory access fault and the runtime kills the process
+// (tools/experiments/pin_probe.hip, scenario munmap_remap_copy, reproduces exactly that; every other
+// staleness scenario - heap reuse, unregistering unmapped ranges, overlapping registrations - is benign).
+// The library cannot see a munmap, so it never keeps a registration it was not explicitly given:
+//  * ss_host_pin(ptr, bytes): the CALLER owns the registration and promises the range stays mapped
+//    until ss_host_unpin(ptr) / ss_host_unpin_all() (a host model with allocatable arrays that live for
+//    the run: pin once after allocation);
+//  * SPARTACUS_PIN_HOST=1: the CALL owns its registrations - made on entry for the arrays of this call
+//    (alive by the contract of the call), dropped before the entry returns.  Nothing of it survives.
+// Ranges never overlap in the registry (a request that partly overlaps an entry is refused and that array
+// stays pageable); a copy whose host range crosses the end of a registration is split there, because the
+// runtime rejects a copy that starts inside a registration and ends outside it (probe: copy_straddles).
 struct PinRegistry {
-  std::map<const void*, size_t> ranges;     // base -> bytes
-  std::map<const void*, char*> devbase;     // base -> the same memory as the device sees it
+  struct Entry { size_t bytes; bool call_owned; };
+  mutable std::mutex mu;                    // plan-API threads copy while host-entry threads pin
+  std::map<const char*, Entry> ranges;      // base -> entry, disjoint
   size_t bytes = 0;
-  // device address of a page-locked host address, or nullptr
-  double* device_view(const void* p, size_t n) const {
+
+  // end of the registration that contains p, or nullptr (caller holds mu)
+  const char* end_of_registration_at(const char* p) const {
     auto it = ranges.upper_bound(p);
     if (it == ranges.begin()) return nullptr;
     --it;
-    if ((const char*)p + n > (const char*)it->first + it->second) return nullptr;
-    auto d = devbase.find(it->first);
-    if (d == devbase.end() || !d->second) return nullptr;
-    return reinterpret_cast<double*>(d->second + ((const char*)p - (const char*)it->first));
+    const char* end = it->first + it->second.bytes;
+    return p < end ? end : nullptr;
   }
   bool covered(const void* p, size_t n) const {
-    auto it = ranges.upper_bound(p);
-    if (it == ranges.begin()) return false;
-    --it;
-    return (const char*)p + n <= (const char*)it->first + it->second;
+    std::lock_guard<std::mutex> lock(mu);
+    const char* end = end_of_registration_at((const char*)p);
+    return end && (const char*)p + n <= end;
   }
-  void pin(const void* p, size_t n) {
-    if (!p || n == 0 || covered(p, n)) return;
-    // drop registrations this range overlaps (the caller re-allocated): hipHostRegister rejects overlaps
+  // how many leading bytes of [p, p + n) one asynchronous copy may take
+  size_t copy_piece(const void* p, size_t n) const {
+    std::lock_guard<std::mutex> lock(mu);
+    if (ranges.empty()) return n;
+    const char* end = end_of_registration_at((const char*)p);
+    if (!end) return n;                     // starts outside every registration: the runtime stages it
+    return std::min(n, (size_t)(end - (const char*)p));
+  }
+  bool pin(const void* p, size_t n, bool call_owned) {
+    if (!p || n == 0) return true;
+    std::lock_guard<std::mutex> lock(mu);
+    const char *a = (const char*)p, *b = a + n;
+    const char* end = end_of_registration_at(a);
+    if (end && b <= end) return true;       // already page-locked
+    // partial overlap with an entry: refuse (never unregister what someone else owns and may be using)
+    auto it = ranges.lower_bound(a);
+    if (end || (it != ranges.end() && it->first < b)) return false;
+    if (hipHostRegister(const_cast<void*>(p), n, hipHostRegisterDefault) != hipSuccess) {
+      (void)hipGetLastError();              // stays pageable: slower, still correct
+      return false;
+    }
+    ranges[a] = {n, call_owned};
+    bytes += n;
+    return true;
+  }
+  // caller: nothing queued may still use the ranges (the host entry synchronises first)
+  void release(bool call_owned_only, const void* only_base = nullptr) {
+    std::lock_guard<std::mutex> lock(mu);
     for (auto it = ranges.begin(); it != ranges.end();) {
-      const char *a = (const char*)it->first, *b = a + it->second;
-      if (a < (const char*)p + n && (const char*)p < b) {
-        hipHostUnregister(const_cast<void*>(it->first));
-        bytes -= it->second;
-        devbase.erase(it->first);
-        it = ranges.erase(it);
-      } else {
-        ++it;
-      }
-    }
-    if (hipHostRegister(const_cast<void*>(p), n, hipHostRegisterMapped) == hipSuccess) {
-      ranges[p] = n;
-      bytes += n;
-      void* d = nullptr;
-      if (hipHostGetDevicePointer(&d, const_cast<void*>(p), 0) == hipSuccess) devbase[p] = static_cast<char*>(d);
-      else (void)hipGetLastError();
-    } else {
-      (void)hipGetLastError();      // stays pageable: slower, still correct
+      if ((call_owned_only && !it->second.call_owned) || (only_base && it->first != (const char*)only_base)) { ++it; continue; }
+      if (hipHostUnregister(const_cast<char*>(it->first)) != hipSuccess) (void)hipGetLastError();
+      bytes -= it->second.bytes;
+      it = ranges.erase(it);
     }
   }
-  void unpin_all() {
-    for (auto& kv : ranges) hipHostUnregister(const_cast<void*>(kv.first));
-    ranges.clear();
-    devbase.clear();
-    bytes = 0;
-  }
+  size_t pinned_bytes() const { std::lock_guard<std::mutex> lock(mu); return bytes; }
 };
 PinRegistry g_pins;
 
@@ -292,21 +310,22 @@ struct HipBackend {
     HIP_CHECK_THROW(hipMalloc(&p, n ? n : 8));
     return p;
   }
-  // A copy whose host range is only partly page-locked is rejected by the runtime.  That happens
-  // when arrays that were page-locked through this library (SPARTACUS_PIN_HOST / ss_host_pin) have
-  // been freed and the allocator has handed the pages to other arrays - outside the contract of
-  // the pinning option, but no reason to fail: drop every registration and copy again, pageable.
+  // One asynchronous copy per piece of the host range that lies inside ONE registration or outside all
+  // of them (PinRegistry::copy_piece): the runtime rejects a copy that leaves the registration it starts in.
   static void copy_async(void* dst, const void* src, size_t n, hipMemcpyKind kind, hipStream_t s) {
-    hipError_t e = hipMemcpyAsync(dst, src, n, kind, s);
-    if (e == hipErrorInvalidValue && g_pins.bytes > 0) {
-      (void)hipGetLastError();
-      HIP_CHECK_THROW(hipDeviceSynchronize());      // nothing may still be reading a registration
-      g_pins.unpin_all();
-      e = hipMemcpyAsync(dst, src, n, kind, s);
-    }
-    if (e != hipSuccess) {
-      g_last_error = std::string("hipMemcpyAsync: ") + hipGetErrorString(e);
-      throw e;
+    const bool host_is_src = kind == hipMemcpyHostToDevice;
+    char* d = static_cast<char*>(dst);
+    const char* h = static_cast<const char*>(src);
+    while (n > 0) {
+      const size_t m = g_pins.copy_piece(host_is_src ? (const void*)h : (const void*)d, n);
+      const hipError_t e = hipMemcpyAsync(d, h, m, kind, s);
+      if (e != hipSuccess) {
+        g_last_error = std::string("hipMemcpyAsync: ") + hipGetErrorString(e);
+        throw e;
+      }
+      d += m;
+      h += m;
+      n -= m;
     }
   }
   void free(void* p) { if (p) hipFree(p); }
@@ -470,7 +489,8 @@ struct HipBackend {
       if (!key.urban) fn = key.nreg == 2 ? ss::launch_lw_forest_r2 : ss::launch_lw_forest_r3;
       else fn = key.nreg == 1 ? ss::launch_lw_urban_r1 : key.nreg == 2 ? ss::launch_lw_urban_r2 : ss::launch_lw_urban_r3;
     }
-    hipEvent_t ev[4] = {t.next(), t.next(), t.next(), t.next()};
+    // four span marks + two events for the fallback-stream hand-over of the cooperative orders
+    hipEvent_t ev[6] = {t.next(), t.next(), t.next(), t.next(), t.next(), t.next()};
     const int rc = fn(key.ns, L, pipe_stream(pipe), ev, pipe_stream(0));
     if (rc != 0) {
       // SS_LAUNCH_BAD_RECORD: the plan's record sizes disagree with the kernels' (a build
@@ -549,6 +569,8 @@ struct HostEntry {
       a.first = nullptr;
       HIP_CHECK_THROW(hipMalloc(reinterpret_cast<void**>(&a.first), std::max<size_t>(elems, 1) * sizeof(double)));
       a.second = elems;
+      // never hand uninitialised device memory towards the caller's arrays (blocking: new arrays are rare)
+      HIP_CHECK_THROW(hipMemset(a.first, 0, std::max<size_t>(elems, 1) * sizeof(double)));
     }
     return a.first;
   }
@@ -575,44 +597,64 @@ struct HostEntry {
 HostEntry g_host;           // deliberately never destroyed at process exit (HIP may be gone)
 
 
+// SPARTACUS_PIN_HOST=1: page-lock the slices of the caller's arrays this call touches - columns
+// [c0, c1), packed layers [l0, l1) - as registrations OWNED BY THE CALL (dropped before it returns).
 void pin_call_arrays(const ss_config* cfg, const ss_canopy* can, const ss_sw_spectral* sw, const ss_lw_spectral* lw,
-                     ss_bc_out* bc, ss_flux* const* fl) {
-  const size_t nc = (size_t)can->ncol, nl = (size_t)can->ntotlay, D = sizeof(double);
-  g_pins.pin(can->cos_sza, nc * D);
+                     ss_bc_out* bc, ss_flux* const* fl, long c0, long c1, long l0, long l1) {
+  const size_t nc = (size_t)(c1 - c0), nl = (size_t)(l1 - l0), D = sizeof(double);
+  auto cols = [&](const double* p, size_t w) { if (p) g_pins.pin(p + w * (size_t)c0, w * nc * D, true); };
+  auto lays = [&](const double* p, size_t w) { if (p && nl) g_pins.pin(p + w * (size_t)l0, w * nl * D, true); };
+  cols(can->cos_sza, 1);
   const double* lay[] = {can->dz, can->building_fraction, can->veg_fraction, can->building_scale, can->veg_scale,
                          can->veg_ext, can->veg_fsd, can->veg_contact_fraction};
-  for (const double* p : lay) g_pins.pin(p, nl * D);
+  for (const double* p : lay) lays(p, 1);
   if (sw && cfg->do_sw) {
     const size_t S = (size_t)cfg->nsw;
     const double* a[] = {sw->air_ext, sw->air_ssa, sw->veg_ssa, sw->roof_albedo, sw->wall_albedo, sw->roof_albedo_dir,
                          sw->wall_specular_frac};
-    for (const double* p : a) g_pins.pin(p, S * nl * D);
-    g_pins.pin(sw->ground_albedo, S * nc * D);
-    g_pins.pin(sw->ground_albedo_dir, S * nc * D);
+    for (const double* p : a) lays(p, S);
+    cols(sw->ground_albedo, S);
+    cols(sw->ground_albedo_dir, S);
   }
   if (lw && cfg->do_lw) {
     const size_t W = (size_t)cfg->nlw;
     const double* a[] = {lw->air_ext, lw->air_ssa, lw->veg_ssa, lw->clear_air_planck, lw->veg_planck,
                          lw->veg_air_planck, lw->roof_emissivity, lw->wall_emissivity, lw->roof_emission,
                          lw->wall_emission};
-    for (const double* p : a) g_pins.pin(p, W * nl * D);
-    g_pins.pin(lw->ground_emissivity, W * nc * D);
-    g_pins.pin(lw->ground_emission, W * nc * D);
+    for (const double* p : a) lays(p, W);
+    cols(lw->ground_emissivity, W);
+    cols(lw->ground_emission, W);
   }
-  g_pins.pin(bc->sw_albedo, (size_t)cfg->nsw * nc * D);
-  g_pins.pin(bc->sw_albedo_dir, (size_t)cfg->nsw * nc * D);
-  g_pins.pin(bc->lw_emissivity, (size_t)cfg->nlw * nc * D);
-  g_pins.pin(bc->lw_emission, (size_t)cfg->nlw * nc * D);
+  cols(bc->sw_albedo, (size_t)cfg->nsw);
+  cols(bc->sw_albedo_dir, (size_t)cfg->nsw);
+  cols(bc->lw_emissivity, (size_t)cfg->nlw);
+  cols(bc->lw_emission, (size_t)cfg->nlw);
   for (int k = 0; k < 4; ++k) {
     if (!fl[k]) continue;
     const size_t ns = (size_t)(k < 2 ? cfg->nsw : cfg->nlw);
     double* const* m = &fl[k]->ground_dn;
     for (int F = 0; F < ss::F_NFIELDS; ++F) {
       const int shape = ss::flux_field_shape(F);
-      const size_t n = shape == 0 ? ns * nc : shape == 1 ? ns * nl : shape == 2 ? nc : nl;
-      g_pins.pin(m[F], n * D);
+      if (shape == 0) cols(m[F], ns);
+      else if (shape == 1) lays(m[F], ns);
+      else if (shape == 2) cols(m[F], 1);
+      else lays(m[F], 1);
     }
   }
+}
+
+// packed-layer range [l0, l1) (0-based) of the columns [c0, c1)
+void layer_range(const ss_canopy* can, int c0, int c1, long* l0_out, long* l1_out) {
+  long l0 = -1, l1 = 0;
+  for (int j = c0; j < c1; ++j) {
+    if (can->nlay[j] <= 0) continue;
+    const long a = can->istartlay[j] - 1;
+    if (l0 < 0 || a < l0) l0 = a;
+    l1 = std::max(l1, a + can->nlay[j]);
+  }
+  if (l0 < 0) l0 = l1 = 0;
+  *l0_out = l0;
+  *l1_out = l1;
 }
 
 struct ChunkView {
@@ -632,14 +674,8 @@ T* adv(T* p, long off) { return p ? p + off : nullptr; }
 // columns [c0, c1) (0-based) of the caller's objects as objects of their own
 void make_view(const ss_canopy* can, const ss_sw_spectral* sw, const ss_lw_spectral* lw, ss_bc_out* bc,
                ss_flux* const* fl, int nsw, int nlw, int c0, int c1, ChunkView& v) {
-  long l0 = -1, l1 = 0;
-  for (int j = c0; j < c1; ++j) {
-    if (can->nlay[j] <= 0) continue;
-    const long a = can->istartlay[j] - 1;
-    if (l0 < 0 || a < l0) l0 = a;
-    l1 = std::max(l1, a + can->nlay[j]);
-  }
-  if (l0 < 0) l0 = l1 = 0;
+  long l0, l1;
+  layer_range(can, c0, c1, &l0, &l1);
   v.istartlay.resize(c1 - c0);
   for (int j = c0; j < c1; ++j)
     v.istartlay[j - c0] = can->nlay[j] > 0 ? (int32_t)(can->istartlay[j] - l0) : 1;
@@ -706,7 +742,10 @@ struct ColumnOutput {
   double* host;
   int width;
 };
-std::vector<ColumnOutput> column_outputs(const ss_config* cfg, ss_bc_out* bc, ss_flux* const* fl) {
+// Only the members a plan of this configuration allocates and writes (flux_member_present): a caller
+// may pass more (an LW flux object with its *_dir members allocated, roof members without do_urban);
+// those stay untouched, exactly as the per-chunk download skips device arrays the plan does not have.
+std::vector<ColumnOutput> column_outputs(const ss_config* cfg, int profiles, ss_bc_out* bc, ss_flux* const* fl) {
   static const char* obj[4] = {"sw_norm_dir", "sw_norm_diff", "lw_internal", "lw_norm"};
   std::vector<ColumnOutput> out;
   if (cfg->do_sw) {
@@ -722,7 +761,7 @@ std::vector<ColumnOutput> column_outputs(const ss_config* cfg, ss_bc_out* bc, ss
     double* const* m = &fl[k]->ground_dn;
     for (int F = 0; F < ss::F_NFIELDS; ++F) {
       const int shape = ss::flux_field_shape(F);
-      if ((shape == 0 || shape == 2) && m[F])
+      if ((shape == 0 || shape == 2) && m[F] && ss::flux_member_present_for(*cfg, profiles != 0, F, k < 2))
         out.push_back({std::string(obj[k]) + "." + HipPlan::flux_field_name(F), m[F],
                        shape == 0 ? (k < 2 ? cfg->nsw : cfg->nlw) : 1});
     }
@@ -932,20 +971,34 @@ int ss_host_pin(const void* ptr, int64_t bytes) {
   int rc = device_ready();
   if (rc) return rc;
   std::lock_guard<std::mutex> lock(g_device_mutex);
-  g_pins.pin(ptr, (size_t)bytes);
-  return g_pins.covered(ptr, (size_t)bytes) ? SS_OK : SS_ERR_HIP;
+  if (!g_pins.pin(ptr, (size_t)bytes, /*call_owned=*/false)) {
+    g_last_error = "ss_host_pin: range overlaps another registration or cannot be page-locked";
+    return SS_ERR_HIP;
+  }
+  return SS_OK;
+}
+
+// The caller's side of the contract of ss_host_pin: before freeing a pinned array.  Waits for the
+// device first (a queued copy must not lose its registration).
+int ss_host_unpin(const void* ptr) {
+  if (!ptr) return SS_ERR_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lock(g_device_mutex);
+  (void)hipDeviceSynchronize();
+  g_pins.release(false, ptr);
+  return SS_OK;
 }
 
 int ss_host_unpin_all(void) {
   std::lock_guard<std::mutex> lock(g_device_mutex);
-  g_pins.unpin_all();
+  (void)hipDeviceSynchronize();
+  g_pins.release(false);
   return SS_OK;
 }
 
 int ss_host_pinned_bytes(int64_t* bytes) {
   if (!bytes) return SS_ERR_BAD_ARGUMENT;
   std::lock_guard<std::mutex> lock(g_device_mutex);
-  *bytes = (int64_t)g_pins.bytes;
+  *bytes = (int64_t)g_pins.pinned_bytes();
   return SS_OK;
 }
 
@@ -971,7 +1024,18 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
   // The reference is called concurrently on disjoint column ranges
   // (spartacus_surface_driver.F90:206-233); one device: serialise.
   std::lock_guard<std::mutex> lock(g_device_mutex);
-  return guarded([&]() {
+  bool pins_made = false;
+  // Whatever happens inside, the entry does not return while the device may still touch the caller's
+  // arrays (asynchronous copies into page-locked memory) and it leaves no call-owned registration behind.
+  auto leave = [&](bool failed) {
+    if (failed) {
+      (void)hipDeviceSynchronize();
+      (void)hipGetLastError();
+      g_host.drop();            // sub-plans with half-done state (pending downloads, bindings) are not reused
+    }
+    if (pins_made) g_pins.release(/*call_owned_only=*/true);
+  };
+  auto body = [&]() -> int {
     const int profiles = ((sw_norm_dir && sw_norm_dir->flux_dn_layer_top)
                           || (lw_internal && lw_internal->flux_dn_layer_top)) ? 1 : 0;
     int device = 0;
@@ -986,13 +1050,26 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
 
     ss_flux* fl[4] = {config->do_sw ? sw_norm_dir : nullptr, config->do_sw ? sw_norm_diff : nullptr,
                       config->do_lw ? lw_internal : nullptr, config->do_lw ? lw_norm : nullptr};
-    if (std::getenv("SPARTACUS_PIN_HOST")) pin_call_arrays(config, canopy, sw, lw, bc_out, fl);
-    // are the caller's (large) arrays page-locked - by the line above or by ss_host_pin?
-    const bool pinned = canopy->dz && g_pins.covered(canopy->dz, sizeof(double) * (size_t)std::max(1, canopy->ntotlay));
-    const bool always_seed = std::getenv("SPARTACUS_ALWAYS_SEED") != nullptr;
     const int c_begin = istartcol - 1, c_end = iendcol;
+    long call_l0 = 0, call_l1 = 0;
+    layer_range(canopy, c_begin, c_end, &call_l0, &call_l1);
+    // SPARTACUS_PIN_HOST=1: registrations owned by this call (PinRegistry); not worth their system calls
+    // for small block calls (SPARTACUS_PIN_HOST_MIN_COLUMNS, default 4096)
+    {
+      const char* pe = std::getenv("SPARTACUS_PIN_HOST");
+      const char* me = std::getenv("SPARTACUS_PIN_HOST_MIN_COLUMNS");
+      const int min_cols = me ? std::atoi(me) : 4096;
+      if (pe && pe[0] != '0' && c_end - c_begin >= min_cols) {
+        pins_made = true;
+        pin_call_arrays(config, canopy, sw, lw, bc_out, fl, c_begin, c_end, call_l0, call_l1);
+      }
+    }
+    // are the caller's (large) arrays page-locked - by the lines above or by ss_host_pin?
+    const bool pinned = canopy->dz && call_l1 > call_l0
+                        && g_pins.covered(canopy->dz + call_l0, sizeof(double) * (size_t)(call_l1 - call_l0));
+    const bool always_seed = std::getenv("SPARTACUS_ALWAYS_SEED") != nullptr;
     // per-column outputs: call-level device arrays, one download per member at the end
-    const std::vector<ColumnOutput> col_out = column_outputs(config, bc_out, fl);
+    const std::vector<ColumnOutput> col_out = column_outputs(config, profiles, bc_out, fl);
     std::vector<double*> col_dev(col_out.size());
     for (size_t i = 0; i < col_out.size(); ++i)
       col_dev[i] = g_host.arena_get(col_out[i].name, (size_t)col_out[i].width * (size_t)(c_end - c_begin));
@@ -1002,8 +1079,7 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
     int r = SS_OK;
     auto fail = [&](HipPlan* p, int code) {
       if (p) g_last_error = p->error;
-      g_host.drop();
-      return code;
+      return code;              // leave() synchronises, then drops the sub-plans
     };
     auto fl_of = [](ChunkView& v, int k) { return v.have_fl[k] ? &v.fl[k] : nullptr; };
     // SPARTACUS_HOST_TIMING=1: wall-clock milliseconds of the host thread per chunk and phase (stderr)
@@ -1026,6 +1102,7 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
       make_view(canopy, sw, lw, bc_out, fl, config->nsw, config->nlw, c0, c1, v);
       const bool fresh = !p;
       if (fresh) p = new HipPlan;
+      p->unbind_externals();      // bindings of an earlier call (other members, other sizes) end here
       for (size_t i = 0; i < col_out.size(); ++i)
         p->bind_external(col_out[i].name, col_dev[i] + (size_t)col_out[i].width * (size_t)(c0 - c_begin),
                          (size_t)col_out[i].width * (size_t)(c1 - c0));
@@ -1084,6 +1161,17 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
     }
     if (timing) std::fprintf(stderr, "host entry total %.2f ms\n", now() - t_start);
     if (nocache) g_host.drop();
+    return r;
+  };
+  return guarded([&]() -> int {
+    int r;
+    try {
+      r = body();
+    } catch (...) {
+      leave(true);
+      throw;
+    }
+    leave(r != SS_OK);
     return r;
   });
 }

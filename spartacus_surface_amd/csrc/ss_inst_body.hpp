@@ -223,10 +223,9 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev, hipStream_t f
       SS_TRY(hipGetLastError());
     }
     if (fallback && fallback != stream) {
-      // second pass on the plan's fallback stream, between two events
-      hipEvent_t a, b;
-      SS_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
-      SS_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+      // second pass on the plan's fallback stream, between two events of the plan's pool (ev[4], ev[5])
+      if (!ev) return (int)hipErrorInvalidValue;
+      const hipEvent_t a = ev[4], b = ev[5];
       SS_TRY(hipEventRecord(a, stream));
       SS_TRY(hipStreamWaitEvent(fallback, a, 0));
       hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0, 2>), glayer, dim3(kBlock), 0,
@@ -234,8 +233,6 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev, hipStream_t f
       SS_TRY(hipGetLastError());
       SS_TRY(hipEventRecord(b, fallback));
       SS_TRY(hipStreamWaitEvent(stream, b, 0));
-      SS_TRY(hipEventDestroy(a));      // (released when the work that uses them has completed)
-      SS_TRY(hipEventDestroy(b));
     } else {
       hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0, 2>), glayer, dim3(kBlock), 0,
                          stream, L);

@@ -124,6 +124,29 @@ inline int eig_nelem(const ClassKey& k) {
     }                                                                  \
   } while (0)
 
+// which canopy_flux members exist (allocate_canopy_flux, radsurf_canopy_flux.F90:96-163)
+inline bool flux_member_present_for(const ss_config& cfg, bool want_profiles, int F, bool use_direct) {
+  switch (F) {
+    case F_GROUND_DN_DIR: case F_TOP_DN_DIR: case F_GROUND_SUNLIT_FRAC:
+      return use_direct;
+    case F_ROOF_IN: case F_ROOF_NET: case F_WALL_IN: case F_WALL_NET:
+      return cfg.do_urban != 0;
+    case F_ROOF_IN_DIR: case F_WALL_IN_DIR: case F_ROOF_SUNLIT_FRAC: case F_WALL_SUNLIT_FRAC:
+      return cfg.do_urban != 0 && use_direct;
+    case F_VEG_ABS: case F_VEG_AIR_ABS:
+      return cfg.do_vegetation != 0;
+    case F_VEG_ABS_DIR: case F_VEG_SUNLIT_FRAC:
+      return cfg.do_vegetation != 0 && use_direct;
+    case F_FLUX_DN_LAYER_TOP: case F_FLUX_UP_LAYER_TOP: case F_FLUX_DN_LAYER_BASE:
+    case F_FLUX_UP_LAYER_BASE:
+      return want_profiles;
+    case F_FLUX_DN_DIR_LAYER_TOP: case F_FLUX_DN_DIR_LAYER_BASE:
+      return want_profiles && use_direct;
+    default:
+      return true;
+  }
+}
+
 template <class Backend>
 class Plan {
  public:
@@ -258,6 +281,14 @@ class Plan {
     dev_cap[name] = elems;
     dev_external[name] = true;
   }
+  // forget every external binding (the owner keeps the memory): the next ensure() of such a name
+  // allocates an array of the plan's own again.  The host entry does this at the start of every
+  // chunk, so that a binding never outlives the call it was made for.
+  void unbind_externals() {
+    for (auto& kv : dev_external)
+      if (kv.second) { dev.erase(kv.first); dev_elems.erase(kv.first); dev_cap.erase(kv.first); }
+    dev_external.clear();
+  }
   void ensure(const std::string& name, size_t elems, size_t elsize = sizeof(double)) {
     auto ex = dev_external.find(name);
     if (ex != dev_external.end() && ex->second) return;
@@ -284,25 +315,7 @@ class Plan {
 
   // which canopy_flux members exist (allocate_canopy_flux, radsurf_canopy_flux.F90:96-163)
   bool flux_member_present(int F, bool use_direct) const {
-    switch (F) {
-      case F_GROUND_DN_DIR: case F_TOP_DN_DIR: case F_GROUND_SUNLIT_FRAC:
-        return use_direct;
-      case F_ROOF_IN: case F_ROOF_NET: case F_WALL_IN: case F_WALL_NET:
-        return cfg.do_urban != 0;
-      case F_ROOF_IN_DIR: case F_WALL_IN_DIR: case F_ROOF_SUNLIT_FRAC: case F_WALL_SUNLIT_FRAC:
-        return cfg.do_urban != 0 && use_direct;
-      case F_VEG_ABS: case F_VEG_AIR_ABS:
-        return cfg.do_vegetation != 0;
-      case F_VEG_ABS_DIR: case F_VEG_SUNLIT_FRAC:
-        return cfg.do_vegetation != 0 && use_direct;
-      case F_FLUX_DN_LAYER_TOP: case F_FLUX_UP_LAYER_TOP: case F_FLUX_DN_LAYER_BASE:
-      case F_FLUX_UP_LAYER_BASE:
-        return want_profiles;
-      case F_FLUX_DN_DIR_LAYER_TOP: case F_FLUX_DN_DIR_LAYER_BASE:
-        return want_profiles && use_direct;
-      default:
-        return true;
-    }
+    return flux_member_present_for(cfg, want_profiles, F, use_direct);
   }
   static const char* flux_field_name(int F) {
     static const char* names[F_NFIELDS] = {

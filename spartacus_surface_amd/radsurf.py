@@ -39,7 +39,7 @@ EXPORTS = (
     "ss_plan_calc_simple_spectrum_lw", "ss_plan_solve", "ss_plan_synchronize",
     "ss_plan_download", "ss_plan_last_kernel_ms", "ss_plan_eigen_failures", "ss_plan_set_pipes", "ss_plan_scale_and_sum", "ss_plan_download_sums",
     "ss_plan_device_ptr", "ss_plan_device", "ss_plan_destroy", "ss_host_entry_plan_creations",
-    "ss_host_pin", "ss_host_unpin_all", "ss_host_pinned_bytes",
+    "ss_host_pin", "ss_host_unpin", "ss_host_unpin_all", "ss_host_pinned_bytes",
     "ss_device_count", "ss_set_device",
     "ss_last_error", "ss_version",
     "ss_calc_matrices_sw_eig", "ss_calc_matrices_lw_eig", "ss_eigen_decomposition_real",
@@ -91,8 +91,32 @@ def set_device(index):
     _check(load_library().ss_set_device(C.c_int32(index)))
 
 
+def host_pin(array):
+    """Page-lock one numpy array for the host entry (ss_host_pin).  CONTRACT: keep the array alive
+    until host_unpin(array) / host_unpin_all() - freeing it first makes a later copy fault the GPU."""
+    _check(load_library().ss_host_pin(C.c_void_p(array.ctypes.data), C.c_int64(array.nbytes)))
+
+
+def host_unpin(array):
+    _check(load_library().ss_host_unpin(C.c_void_p(array.ctypes.data)))
+
+
+def host_arrays(config, canopy_props, sw_spectral_props, lw_spectral_props, bc_out, *fluxes):
+    """Every numpy array of a radsurf argument list that the host entry copies (for host_pin)."""
+    import numpy as np
+    out = []
+    for obj in (canopy_props, sw_spectral_props if config.do_sw else None,
+                lw_spectral_props if config.do_lw else None, bc_out) + tuple(fluxes):
+        if obj is None:
+            continue
+        for v in vars(obj).values():
+            if isinstance(v, np.ndarray) and v.dtype == np.float64 and v.size:
+                out.append(v)
+    return out
+
+
 def host_unpin_all():
-    """Unlock every host array the library page-locked (SPARTACUS_PIN_HOST=1 / ss_host_pin)."""
+    """Unlock every host array page-locked through ss_host_pin."""
     _check(load_library().ss_host_unpin_all())
 
 
