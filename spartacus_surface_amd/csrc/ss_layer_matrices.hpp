@@ -481,6 +481,47 @@ SS_HD int sw_direct_part(const double* g0, const double* dsc0, double dz, const 
   return rc;
 }
 
+// The direct-beam part of a (D) sub-problem embedded at region offset R0 of the (DF x DF) blocks of the
+// record: int_dir = -Gamma0^-1 (schur_invert_sw, radtool_schur.F90:45-51; int_diff = -(G1 + G2)^-1 and
+// int_dir_diff = -2 int_diff (g3 g0i) of the same routine are not formed: the downward sweep applies both
+// to its flux convergences with one solve with G1 + G2) and E = G0 diag(exp(mu dz)) G0^-1 (sw_eig :223-229).
+// Returns the eigen-solver's code; mu, G0, G0^-1 and exp(mu dz) for the particular solutions.
+template <int NF, int DF, int D, int R0, class W>
+SS_HD int sw_direct_embedded(const double* g0, const double* dsc0, double dz, const W& w, double* mu, double* G0,
+                             double* G0inv, double* emu) {
+  using Rec = SwRec<NF, DF>;
+  SS_STAMP_DECL(w.stamps);
+  {
+    double LU0[D * D], g0i[D * D], idir[D * D];
+    mat_copy<D, D>(g0, LU0);
+    lu_factor<D>(LU0);
+    lu_invert<D>(LU0, g0i);
+    SS_UNROLL_FULL
+    for (int k = 0; k < D * D; ++k) idir[k] = -g0i[k];
+    put_embedded<DF, DF, D, D, R0, R0>(w, Rec::IDIR, idir);
+  }
+  SS_STAMP(1);
+  // Gamma0 is symmetric after scaling with sqrt(region fraction)
+  int rc = -1;
+  if constexpr (D >= 3 && D <= SS_UNROLL_MAX) {
+    if (dsc0) rc = eigen_decomposition_scaled_sym<D>(g0, dsc0, mu, G0);
+    if (rc >= 0 && !sym_spectrum_is_well_graded<D>(mu)) rc = -1;
+  }
+  if (rc < 0) rc = eigen_decomposition_real<D>(g0, mu, G0);
+  {
+    double LU0[D * D], t[D * D], Ed[D * D];
+    mat_copy<D, D>(G0, LU0);
+    lu_factor<D>(LU0);
+    lu_invert<D>(LU0, G0inv);
+    SS_UNROLL_N(D)
+    for (int j = 0; j < D; ++j) emu[j] = exp(mu[j] * dz);
+    scale_cols<D>(G0, emu, t);
+    mat_mul<D, D, D>(t, G0inv, Ed);
+    put_embedded<DF, DF, D, D, R0, R0>(w, Rec::EDIR, Ed);
+  }
+  return rc;
+}
+
 // calc_matrices_sw_eig for an (N, D) sub-problem embedded at (I0 = stream
 // offset, R0 = region offset) of the full (NF, DF) record.
 template <int NF, int DF, int N, int D, int I0, int R0, class W>
@@ -493,51 +534,7 @@ SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
   double mu[D], G0[D * D], G0inv[D * D], emu[D];
   double g3v[N * D], g4v[N * D];   // particular solutions, one column per direct eigenvalue
 
-  // schur_invert_sw (radtool_schur.F90:45-51) -> int_dir, int_diff, int_dir_diff
-  {
-    double g0i[D * D];
-    {
-      double LU0[D * D];
-      mat_copy<D, D>(g0, LU0);
-      lu_factor<D>(LU0);
-      lu_invert<D>(LU0, g0i);
-      double idir[D * D];
-      SS_UNROLL_FULL
-      for (int k = 0; k < D * D; ++k) idir[k] = -g0i[k];
-      put_embedded<DF, DF, D, D, R0, R0>(w, Rec::IDIR, idir);
-    }
-    // int_diff = g2i - g1i of the Schur inverse (radtool_schur.F90:45-51), with
-    //   g1i = (G1 - G2 G1^-1 G2)^-1,  g2i = g1i G2 G1^-1.
-    // Since G1 - G2 G1^-1 G2 = (G1 - G2) G1^-1 (G1 + G2), this is
-    //   g1i (G2 G1^-1 - I) = (G1 + G2)^-1 G1 (G1 - G2)^-1 (G2 - G1) G1^-1 = -(G1 + G2)^-1,
-    // and int_dir_diff = 2 g3i = -2 int_diff (g3 g0i).  Neither is formed here: the
-    // downward sweep applies both to its flux convergences with one solve with G1 + G2.
-  }
-
-  SS_STAMP(1);
-  // Section 3 (:223-229): E = G0 diag(exp(mu dz)) G0^-1
-  {
-    // Gamma0 is symmetric after scaling with sqrt(region fraction)
-    int rc = -1;
-    if constexpr (D >= 3 && D <= SS_UNROLL_MAX) {
-      if (dsc0) rc = eigen_decomposition_scaled_sym<D>(g0, dsc0, mu, G0);
-      if (rc >= 0 && !sym_spectrum_is_well_graded<D>(mu)) rc = -1;
-    }
-    if (rc < 0) rc = eigen_decomposition_real<D>(g0, mu, G0);
-    ierr += rc;
-  }
-  {
-    double LU0[D * D], t[D * D];
-    mat_copy<D, D>(G0, LU0);
-    lu_factor<D>(LU0);
-    lu_invert<D>(LU0, G0inv);
-    SS_UNROLL_N(D)
-    for (int j = 0; j < D; ++j) emu[j] = exp(mu[j] * dz);
-    scale_cols<D>(G0, emu, t);
-    double Ed[D * D];
-    mat_mul<D, D, D>(t, G0inv, Ed);
-    put_embedded<DF, DF, D, D, R0, R0>(w, Rec::EDIR, Ed);
-  }
+  ierr += sw_direct_embedded<NF, DF, D, R0>(g0, dsc0, dz, w, mu, G0, G0inv, emu);
 
   // Section 4 (:231-253): the sources of the particular solutions g3, g4, one column
   // per direct eigenvalue; solved inside diffuse_part from the eigen-decomposition

@@ -15,6 +15,7 @@
 #include "ss_geometry.hpp"
 #include "ss_eigen_coop.hpp"
 #include "ss_layer_matrices.hpp"
+#include "ss_layer_sym.hpp"
 #include "ss_solver_sw.hpp"
 #include "ss_pack.hpp"
 #include "ss_layer16.hpp"
@@ -230,6 +231,24 @@ SS_HD void layer_first_lw(const Launch& L, int cu, int jlay, const W& w) {
   }
 }
 
+// Layer matrices of an N sub-problem: in symmetrised coordinates (ss_layer_sym.hpp) where the orders live
+// in registers and the structure is there, else the general route (ss_layer_matrices.hpp).
+// -DSS_NO_SYM_LAYER: general route always (the round-2 form).
+template <int NF, int N, int I0, class W>
+SS_HD int calc_matrices_lw_route(const double* g1, const double* g2, const double* b, const double* dsc, double dz,
+                                 const W& w, const CoopEig* coop = nullptr) {
+#if !defined(SS_NO_SYM_LAYER)
+  if constexpr (N >= 3 && N <= SS_UNROLL_MAX) {
+    if (dsc) {
+      const LaneLds<true> lds{};
+      const int rc = sym::calc_matrices_lw_sym<NF, N, I0>(g1, g2, b, dsc, dz, w, lds);
+      if (rc >= 0) return rc;
+    }
+  }
+#endif
+  return calc_matrices_lw<NF, N, I0>(g1, g2, b, dsc, dz, w, coop);
+}
+
 // W: RecWriter (HBM layer record) or the FusedWriter of k_layer_up (ss_layer_matrices.hpp)
 // (STAGE: see layer_unit_sw)
 template <bool URBAN, int NREG, int NS, class W, int STAGE = 0>
@@ -387,7 +406,7 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
     double s1[NS * NS], s2[NS * NS];
     get_block<N, NS, NS, 0, 0>(g1, s1);
     get_block<N, NS, NS, 0, 0>(g2, s2);
-    ierr = calc_matrices_lw<N, NS, 0>(s1, s2, b, dsc, p.g.dz, w);
+    ierr = calc_matrices_lw_route<N, NS, 0>(s1, s2, b, dsc, p.g.dz, w);
   } else if (STAGE != 1 && p.frac[0] <= L.cfg.min_vegetation_fraction) {
     constexpr int NV = (NREG > 1) ? (NREG - 1) * NS : NS;
     constexpr int IV = (NREG > 1) ? NS : 0;
@@ -395,13 +414,13 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
       double s1[NV * NV], s2[NV * NV];
       get_block<N, NV, NV, IV, IV>(g1, s1);
       get_block<N, NV, NV, IV, IV>(g2, s2);
-      ierr = calc_matrices_lw<N, NV, IV>(s1, s2, b + IV, dsc + IV, p.g.dz, w);
+      ierr = calc_matrices_lw_route<N, NV, IV>(s1, s2, b + IV, dsc + IV, p.g.dz, w);
     } else {
       ierr = 0;
     }
   } else {
     if constexpr (STAGE == 1) ierr = 0;     // (full problems of the first pass went the cooperative way above)
-    else ierr = calc_matrices_lw<N, N, 0>(g1, g2, b, dsc, p.g.dz, w, STAGE == 2 ? &ce : nullptr);
+    else ierr = calc_matrices_lw_route<N, N, 0>(g1, g2, b, dsc, p.g.dz, w, STAGE == 2 ? &ce : nullptr);
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ierr != 0 && L.eigen_fail) atomicAdd(L.eigen_fail, 1ULL);

@@ -18,6 +18,7 @@
 #include "ss_linalg.hpp"
 #include "ss_geometry.hpp"
 #include "ss_layer_matrices.hpp"
+#include "ss_layer_sym.hpp"
 #include "ss_eigen_coop.hpp"
 #include "ss_pack.hpp"
 #include "ss_layer16.hpp"
@@ -159,6 +160,24 @@ SS_HD int calc_matrices_sw(const double* g0, const double* g1, const double* g2,
 template <int NREG>
 SS_HD bool gamma_structure_ok(const double* frac, const double* fx);
 
+// Layer matrices of an (N, D) sub-problem: in symmetrised coordinates (ss_layer_sym.hpp) where the orders
+// live in registers and the structure is there, else the general route (ss_layer_matrices.hpp).
+template <int NF, int DF, int N, int D, int I0, int R0, class W>
+SS_HD int calc_matrices_sw_route(const double* g0, const double* g1, const double* g2, const double* g3,
+                                 const double* dsc0, const double* dsc, double dz, const W& w,
+                                 const CoopEig* coop = nullptr) {
+#if !defined(SS_NO_SYM_LAYER)
+  if constexpr (N >= 3 && N <= SS_UNROLL_MAX) {
+    if (dsc) {
+      const LaneLds<true> lds{};
+      const int rc = sym::calc_matrices_sw_sym<NF, DF, N, D, I0, R0>(g0, g1, g2, g3, dsc0, dsc, dz, w, lds);
+      if (rc >= 0) return rc;
+    }
+  }
+#endif
+  return calc_matrices_sw<NF, DF, N, D, I0, R0>(g0, g1, g2, g3, dsc0, dsc, dz, w, coop);
+}
+
 // First pass of the layer kernel for the orders the row-of-16 kernels take (see layer_first_lw)
 template <bool URBAN, int NREG, int NS, class W>
 SS_HD void layer_first_sw(const Launch& L, int cu, int jlay, const W& w) {
@@ -233,7 +252,7 @@ SS_HD void layer_first_sw(const Launch& L, int cu, int jlay, const W& w) {
       s3[I] = sw_gamma3_own<URBAN, NREG>(lg, p, 0, I);
       dsc[I] = dsc0[0] * lg.sqrt_wmu[I];
     });
-    ierr = calc_matrices_sw<N, D, NS, 1, 0, 0>(s0, s1, s2, s3, dsc0, dsc, p.g.dz, w, nullptr);
+    ierr = calc_matrices_sw_route<N, D, NS, 1, 0, 0>(s0, s1, s2, s3, dsc0, dsc, p.g.dz, w, nullptr);
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ierr != 0 && L.eigen_fail) atomicAdd(L.eigen_fail, 1ULL);
@@ -460,7 +479,7 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
     get_block<N, NS, NS, 0, 0>(g1, s1);
     get_block<N, NS, NS, 0, 0>(g2, s2);
     get_block<N, NS, 1, 0, 0>(g3, s3);
-    ierr = calc_matrices_sw<N, D, NS, 1, 0, 0>(s0, s1, s2, s3, dsc0, dsc, g.dz, w);
+    ierr = calc_matrices_sw_route<N, D, NS, 1, 0, 0>(s0, s1, s2, s3, dsc0, dsc, g.dz, w);
   } else if (STAGE != 1 && frac[0] <= L.cfg.min_vegetation_fraction) {
     // vegetated regions only: (ns+1:n, 2:nreg)
     constexpr int NV = (NREG > 1) ? (NREG - 1) * NS : NS;
@@ -473,13 +492,13 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
       get_block<N, NV, NV, IV, IV>(g1, s1);
       get_block<N, NV, NV, IV, IV>(g2, s2);
       get_block<N, NV, DV, IV, RV>(g3, s3);
-      ierr = calc_matrices_sw<N, D, NV, DV, IV, RV>(s0, s1, s2, s3, dsc0 + RV, dsc + IV, g.dz, w);
+      ierr = calc_matrices_sw_route<N, D, NV, DV, IV, RV>(s0, s1, s2, s3, dsc0 + RV, dsc + IV, g.dz, w);
     } else {
       ierr = 0;
     }
   } else {
     if constexpr (STAGE == 1) ierr = 0;     // (full problems of the first pass went the cooperative way above)
-    else ierr = calc_matrices_sw<N, D, N, D, 0, 0>(g0, g1, g2, g3, dsc0, dsc, g.dz, w, STAGE == 2 ? &ce : nullptr);
+    else ierr = calc_matrices_sw_route<N, D, N, D, 0, 0>(g0, g1, g2, g3, dsc0, dsc, g.dz, w, STAGE == 2 ? &ce : nullptr);
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ierr != 0 && L.eigen_fail) atomicAdd(L.eigen_fail, 1ULL);
