@@ -227,6 +227,7 @@ struct LwFusedWriter {
       rec_pair_store(crec + (long)(CRec::ISRC + e - LRec::ISRC) * stride, v0, v1);
     }
   }
+  SS_HD const Lds& scratch() const { return *lds; }   // the slots are free until R and T are put
 };
 
 // Layer matrices and adding step of every layer of a column unit on one lane (k_layer_up, see

@@ -91,6 +91,26 @@ struct LaneLds {
   SS_HD double get(int slot) const { return a[slot]; }
 #endif
 };
+// A smaller per-lane scratch of SLOTS doubles, same addressing (the graded-order permutation of the
+// symmetrised layer route, ss_layer_sym.hpp, in kernels that stage nothing else in LDS: 36 slots =
+// 18 KB per wave, two waves per SIMD fit the 160 KB of a CU)
+template <int SLOTS>
+struct LaneLdsN {
+  static constexpr int kSlots = SLOTS;
+#if defined(__HIP_DEVICE_COMPILE__)
+  double* p;
+  SS_HD LaneLdsN() {
+    __shared__ double lds[SLOTS * 64];
+    p = lds + threadIdx.x;
+  }
+  SS_HD void put(int slot, double v) const { p[slot * 64] = v; }
+  SS_HD double get(int slot) const { return p[slot * 64]; }
+#else
+  mutable double a[SLOTS] = {};
+  SS_HD void put(int slot, double v) const { a[slot] = v; }
+  SS_HD double get(int slot) const { return a[slot]; }
+#endif
+};
 // Orders above SS_UNROLL_MAX run four waves per SIMD: no LDS to spare, nothing staged
 template <>
 struct LaneLds<false> {

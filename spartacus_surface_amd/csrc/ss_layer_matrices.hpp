@@ -145,6 +145,16 @@ struct RecWriter {
   SS_HD void put2(int e, double v0, double v1) const {
     rec_pair_store(rec + (long)e * stride, v0, v1);
   }
+  // per-lane LDS scratch for the unit that writes through this writer (ss_layer_sym.hpp)
+  SS_HD LaneLdsN<36> scratch() const { return LaneLdsN<36>{}; }
+};
+// Writer into a plain array (the cold general route of the small orders: its record is replayed through
+// the real writer afterwards, see calc_matrices_*_route)
+struct ArrayRecWriter {
+  double* rec;
+  unsigned long long* stamps;
+  SS_HD void put2(int e, double v0, double v1) const { rec[e] = v0; rec[e + 1] = v1; }
+  SS_HD LaneLdsN<36> scratch() const { return LaneLdsN<36>{}; }
 };
 
 // ---- fused layer + upward-sweep kernels (orders that live in registers) ----
@@ -202,6 +212,7 @@ struct FusedWriter {
       if (e >= FWD0) rec_pair_store(crec + (long)(FWD_AT + e - FWD0) * stride, v0, v1);
     }
   }
+  SS_HD const Lds& scratch() const { return *lds; }   // the slots are free until R and T are put
 };
 
 // Sources of the adding step: the HBM layer record (three-kernel form) ...

@@ -232,26 +232,30 @@ SS_HD void layer_first_lw(const Launch& L, int cu, int jlay, const W& w) {
 }
 
 // Layer matrices of an N sub-problem: in symmetrised coordinates (ss_layer_sym.hpp) where the orders live
-// in registers and the structure is there, else the general route (ss_layer_matrices.hpp).
-// -DSS_NO_SYM_LAYER: general route always (the round-2 form).
-template <int NF, int N, int I0, class W>
+// in registers - returns -1, nothing written, when the unit declines (the caller then sends the whole unit
+// to the out-of-line general route, layer_unit_lw_cold) -, else the general route (ss_layer_matrices.hpp).
+// GENERAL: general route whatever the order (the cold unit itself; -DSS_NO_SYM_LAYER: always, the round-2 form).
+template <int NF, int N, int I0, bool GENERAL, class W>
 SS_HD int calc_matrices_lw_route(const double* g1, const double* g2, const double* b, const double* dsc, double dz,
                                  const W& w, const CoopEig* coop = nullptr) {
 #if !defined(SS_NO_SYM_LAYER)
-  if constexpr (N >= 3 && N <= SS_UNROLL_MAX) {
-    if (dsc) {
-      const LaneLds<true> lds{};
-      const int rc = sym::calc_matrices_lw_sym<NF, N, I0>(g1, g2, b, dsc, dz, w, lds);
-      if (rc >= 0) return rc;
-    }
+  if constexpr (!GENERAL && N >= 3 && N <= SS_UNROLL_MAX) {
+    int rc = -1;
+    if (dsc) rc = sym::calc_matrices_lw_sym<NF, N, I0>(g1, g2, b, dsc, dz, w, w.scratch());
+    // sub-problems of the orders above SS_UNROLL_MAX (second pass of the layer kernel, itself the slow
+    // path): general route in line; the small orders hand the decline to their caller
+    if (rc >= 0 || NF <= SS_UNROLL_MAX) return rc;
   }
 #endif
   return calc_matrices_lw<NF, N, I0>(g1, g2, b, dsc, dz, w, coop);
 }
 
+template <bool URBAN, int NREG, int NS>
+SS_HD_NOINLINE void layer_unit_lw_cold(const Launch& L, int cu, int jlay, double* rec);
+
 // W: RecWriter (HBM layer record) or the FusedWriter of k_layer_up (ss_layer_matrices.hpp)
 // (STAGE: see layer_unit_sw)
-template <bool URBAN, int NREG, int NS, class W, int STAGE = 0>
+template <bool URBAN, int NREG, int NS, class W, int STAGE = 0, bool GENERAL = false>
 SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
   SS_STAMP_DECL((unsigned long long*)L.eigen_fail);
   constexpr int N = NREG * NS;
@@ -406,7 +410,7 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
     double s1[NS * NS], s2[NS * NS];
     get_block<N, NS, NS, 0, 0>(g1, s1);
     get_block<N, NS, NS, 0, 0>(g2, s2);
-    ierr = calc_matrices_lw_route<N, NS, 0>(s1, s2, b, dsc, p.g.dz, w);
+    ierr = calc_matrices_lw_route<N, NS, 0, GENERAL>(s1, s2, b, dsc, p.g.dz, w);
   } else if (STAGE != 1 && p.frac[0] <= L.cfg.min_vegetation_fraction) {
     constexpr int NV = (NREG > 1) ? (NREG - 1) * NS : NS;
     constexpr int IV = (NREG > 1) ? NS : 0;
@@ -414,19 +418,37 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
       double s1[NV * NV], s2[NV * NV];
       get_block<N, NV, NV, IV, IV>(g1, s1);
       get_block<N, NV, NV, IV, IV>(g2, s2);
-      ierr = calc_matrices_lw_route<N, NV, IV>(s1, s2, b + IV, dsc + IV, p.g.dz, w);
+      ierr = calc_matrices_lw_route<N, NV, IV, GENERAL>(s1, s2, b + IV, dsc + IV, p.g.dz, w);
     } else {
       ierr = 0;
     }
   } else {
     if constexpr (STAGE == 1) ierr = 0;     // (full problems of the first pass went the cooperative way above)
-    else ierr = calc_matrices_lw_route<N, N, 0>(g1, g2, b, dsc, p.g.dz, w, STAGE == 2 ? &ce : nullptr);
+    else ierr = calc_matrices_lw_route<N, N, 0, GENERAL>(g1, g2, b, dsc, p.g.dz, w, STAGE == 2 ? &ce : nullptr);
+  }
+  if constexpr (!GENERAL && STAGE == 0 && N <= SS_UNROLL_MAX) {
+    if (ierr < 0) {
+      // declined by the symmetrised route (nothing written yet): the whole unit again, general route, out of
+      // line - the cold path must not keep the Gamma matrices of this path alive, nor set its register budget
+      double rec[LwRec<N>::NELEM];
+      for (int k = 0; k < LwRec<N>::NELEM; ++k) rec[k] = 0.0;
+      layer_unit_lw_cold<URBAN, NREG, NS>(L, cu, jlay, rec);
+      SS_UNROLL_FULL
+      for (int e = 0; e < LwRec<N>::NELEM; e += 2) w.put2(e, rec[e], rec[e + 1]);
+      return;
+    }
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ierr != 0 && L.eigen_fail) atomicAdd(L.eigen_fail, 1ULL);
 #else
   if (ierr != 0 && L.eigen_fail) *L.eigen_fail += 1ULL;
 #endif
+}
+
+template <bool URBAN, int NREG, int NS>
+SS_HD_NOINLINE void layer_unit_lw_cold(const Launch& L, int cu, int jlay, double* rec) {
+  const ArrayRecWriter w{rec, nullptr};
+  layer_unit_lw<URBAN, NREG, NS, ArrayRecWriter, 0, true>(L, cu, jlay, w);
 }
 
 template <bool URBAN, int NREG, int NS, int STAGE = 0>

@@ -161,22 +161,24 @@ template <int NREG>
 SS_HD bool gamma_structure_ok(const double* frac, const double* fx);
 
 // Layer matrices of an (N, D) sub-problem: in symmetrised coordinates (ss_layer_sym.hpp) where the orders
-// live in registers and the structure is there, else the general route (ss_layer_matrices.hpp).
-template <int NF, int DF, int N, int D, int I0, int R0, class W>
+// live in registers - returns -1, nothing written, when the unit declines (the caller then sends the whole
+// unit to the out-of-line general route, layer_unit_sw_cold) -, else the general route (ss_layer_matrices.hpp).
+template <int NF, int DF, int N, int D, int I0, int R0, bool GENERAL, class W>
 SS_HD int calc_matrices_sw_route(const double* g0, const double* g1, const double* g2, const double* g3,
                                  const double* dsc0, const double* dsc, double dz, const W& w,
                                  const CoopEig* coop = nullptr) {
 #if !defined(SS_NO_SYM_LAYER)
-  if constexpr (N >= 3 && N <= SS_UNROLL_MAX) {
-    if (dsc) {
-      const LaneLds<true> lds{};
-      const int rc = sym::calc_matrices_sw_sym<NF, DF, N, D, I0, R0>(g0, g1, g2, g3, dsc0, dsc, dz, w, lds);
-      if (rc >= 0) return rc;
-    }
+  if constexpr (!GENERAL && N >= 3 && N <= SS_UNROLL_MAX) {
+    int rc = -1;
+    if (dsc) rc = sym::calc_matrices_sw_sym<NF, DF, N, D, I0, R0>(g0, g1, g2, g3, dsc0, dsc, dz, w, w.scratch());
+    if (rc >= 0 || NF <= SS_UNROLL_MAX) return rc;      // (see calc_matrices_lw_route)
   }
 #endif
   return calc_matrices_sw<NF, DF, N, D, I0, R0>(g0, g1, g2, g3, dsc0, dsc, dz, w, coop);
 }
+
+template <bool URBAN, int NREG, int NS>
+SS_HD_NOINLINE void layer_unit_sw_cold(const Launch& L, int cu, int jlay, double* rec);
 
 // First pass of the layer kernel for the orders the row-of-16 kernels take (see layer_first_lw)
 template <bool URBAN, int NREG, int NS, class W>
@@ -252,7 +254,7 @@ SS_HD void layer_first_sw(const Launch& L, int cu, int jlay, const W& w) {
       s3[I] = sw_gamma3_own<URBAN, NREG>(lg, p, 0, I);
       dsc[I] = dsc0[0] * lg.sqrt_wmu[I];
     });
-    ierr = calc_matrices_sw_route<N, D, NS, 1, 0, 0>(s0, s1, s2, s3, dsc0, dsc, p.g.dz, w, nullptr);
+    ierr = calc_matrices_sw_route<N, D, NS, 1, 0, 0, true>(s0, s1, s2, s3, dsc0, dsc, p.g.dz, w, nullptr);
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ierr != 0 && L.eigen_fail) atomicAdd(L.eigen_fail, 1ULL);
@@ -274,7 +276,7 @@ SS_HD void layer_first_sw(const Launch& L, int cu, int jlay, const W& w) {
 // STAGE (orders of the cooperative eigen-solver, ss_eigen_coop.hpp): 0 = everything here;
 // 1 = first pass: only the factor W of the full problem goes to the eigen record;
 // 2 = second pass: everything, with the eigen-decomposition taken from the record.
-template <bool URBAN, int NREG, int NS, class W, int STAGE = 0>
+template <bool URBAN, int NREG, int NS, class W, int STAGE = 0, bool GENERAL = false>
 SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
   SS_STAMP_DECL((unsigned long long*)L.eigen_fail);
   constexpr int N = NREG * NS, D = NREG;
@@ -479,7 +481,7 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
     get_block<N, NS, NS, 0, 0>(g1, s1);
     get_block<N, NS, NS, 0, 0>(g2, s2);
     get_block<N, NS, 1, 0, 0>(g3, s3);
-    ierr = calc_matrices_sw_route<N, D, NS, 1, 0, 0>(s0, s1, s2, s3, dsc0, dsc, g.dz, w);
+    ierr = calc_matrices_sw_route<N, D, NS, 1, 0, 0, GENERAL>(s0, s1, s2, s3, dsc0, dsc, g.dz, w);
   } else if (STAGE != 1 && frac[0] <= L.cfg.min_vegetation_fraction) {
     // vegetated regions only: (ns+1:n, 2:nreg)
     constexpr int NV = (NREG > 1) ? (NREG - 1) * NS : NS;
@@ -492,19 +494,36 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
       get_block<N, NV, NV, IV, IV>(g1, s1);
       get_block<N, NV, NV, IV, IV>(g2, s2);
       get_block<N, NV, DV, IV, RV>(g3, s3);
-      ierr = calc_matrices_sw_route<N, D, NV, DV, IV, RV>(s0, s1, s2, s3, dsc0 + RV, dsc + IV, g.dz, w);
+      ierr = calc_matrices_sw_route<N, D, NV, DV, IV, RV, GENERAL>(s0, s1, s2, s3, dsc0 + RV, dsc + IV, g.dz, w);
     } else {
       ierr = 0;
     }
   } else {
     if constexpr (STAGE == 1) ierr = 0;     // (full problems of the first pass went the cooperative way above)
-    else ierr = calc_matrices_sw_route<N, D, N, D, 0, 0>(g0, g1, g2, g3, dsc0, dsc, g.dz, w, STAGE == 2 ? &ce : nullptr);
+    else ierr = calc_matrices_sw_route<N, D, N, D, 0, 0, GENERAL>(g0, g1, g2, g3, dsc0, dsc, g.dz, w, STAGE == 2 ? &ce : nullptr);
+  }
+  if constexpr (!GENERAL && STAGE == 0 && N <= SS_UNROLL_MAX) {
+    if (ierr < 0) {
+      // declined by the symmetrised route (nothing written yet): the whole unit again, out of line
+      double rec[SwRec<N, D>::NELEM];
+      for (int k = 0; k < SwRec<N, D>::NELEM; ++k) rec[k] = 0.0;
+      layer_unit_sw_cold<URBAN, NREG, NS>(L, cu, jlay, rec);
+      SS_UNROLL_FULL
+      for (int e = 0; e < SwRec<N, D>::NELEM; e += 2) w.put2(e, rec[e], rec[e + 1]);
+      return;
+    }
   }
 #if defined(__HIP_DEVICE_COMPILE__)
   if (ierr != 0 && L.eigen_fail) atomicAdd(L.eigen_fail, 1ULL);
 #else
   if (ierr != 0 && L.eigen_fail) *L.eigen_fail += 1ULL;
 #endif
+}
+
+template <bool URBAN, int NREG, int NS>
+SS_HD_NOINLINE void layer_unit_sw_cold(const Launch& L, int cu, int jlay, double* rec) {
+  const ArrayRecWriter w{rec, nullptr};
+  layer_unit_sw<URBAN, NREG, NS, ArrayRecWriter, 0, true>(L, cu, jlay, w);
 }
 
 template <bool URBAN, int NREG, int NS, int STAGE = 0>
