@@ -18,7 +18,10 @@ template <int N>
 struct LwColRec {
   static constexpr int PDN = 0;                       // P = Den^-1 T      N x N   (Den = I - a_above R)
   static constexpr int ABE = PDN + rec_even(N * N);   // a_below(l+1)      N x N (canopy part)
-  static constexpr int SBE = ABE + rec_even(N * N);   // source_below(l+1) N (canopy part)
+  // (the small orders store D^-1 a_below D as a packed lower triangle: see SwColRec)
+  static constexpr bool PACKED = sym_packed(N, true);
+  static constexpr int NAB = PACKED ? tri_count(N) : N * N;
+  static constexpr int SBE = ABE + rec_even(NAB);     // source_below(l+1) N (canopy part)
   static constexpr int RSD = SBE + rec_even(N);       // Den^-1 (R source_above + source_lay)  N
   // fused layer + upward kernel (fused_order(N)): what the downward sweep reads of the layer
   // matrices travels here - int_flux_mat (N x N) and int_source (N)
@@ -87,16 +90,26 @@ SS_HD void lw_ground(const Launch& L, long cidx, int l0, double* Aab, double* Sa
 
 // Adding step of one layer: R, T, source_lay from "src"; stores a_below, source_below and the
 // operators of the downward sweep into the column record
+// dsc, rd: scaling of the layer's components and its reciprocal (layer_scaling; read where the records are packed)
 template <int N, class Src>
-SS_HD void lw_up_step(const Src& src, const double* Aab, const double* Sab, double* crec, double* Abe, double* Sbe) {
-  using LRec = LwRec<N>;
+SS_HD void lw_up_step(const Src& src, const double* Aab, const double* Sab, double* crec, double* Abe, double* Sbe,
+                      const double* dsc, const double* rd) {
+  using LRec = LwLayRec<N>;
   using CRec = LwColRec<N>;
   constexpr long stride = kRecStride;
   double R[N * N], T[N * N], Den[N * N], Sl[N];
-  src.template load<N * N>(LRec::R, R);
-  src.template load<N * N>(LRec::T, T);
+  if constexpr (LRec::PACKED) {
+    load_packed_unscaled<N>(src, LRec::R, dsc, rd, R);
+    load_packed_unscaled<N>(src, LRec::T, dsc, rd, T);
+  } else {
+    src.template load<N * N>(LRec::R, R);
+    src.template load<N * N>(LRec::T, T);
+  }
   src.template load<N>(LRec::SRC, Sl);
   lw_adding_step<N>(Aab, Sab, R, T, Sl, Den, Abe, Sbe);
+  if constexpr (CRec::PACKED) {
+    store_packed_scaled<N>(crec, stride, CRec::ABE, Abe, dsc, rd);
+  } else
   rec_store<N * N>(crec, stride, CRec::ABE, Abe);
   rec_store<N>(crec, stride, CRec::SBE, Sbe);
   // operators of the downward sweep
@@ -183,7 +196,7 @@ SS_HD void lw_top(const Launch& L, long cidx, const double* Aab, const double* S
 template <bool URBAN, int NREG, int NS>
 SS_HD void column_up_lw(const Launch& L, int cu) {
   constexpr int N = NREG * NS;
-  using LRec = LwRec<N>;
+  using LRec = LwLayRec<N>;
   using CRec = LwColRec<N>;
   const Inputs& in = L.in;
   const int col = L.cols[cu / L.nspec];
@@ -197,7 +210,14 @@ SS_HD void column_up_lw(const Launch& L, int cu) {
     const RecSource src{L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu), kRecStride};
     double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
     double Abe[N * N], Sbe[N];
-    lw_up_step<N>(src, Aab, Sab, crec, Abe, Sbe);
+    double dsc[N], rd[N];
+    if constexpr (LRec::PACKED || CRec::PACKED) {
+      double vf, bf, frac[NREG];
+      pack_fractions(pack_rec(L, jlay, cu, kPackLw), vf, bf);
+      region_fractions<URBAN, true, NREG>(vf, bf, frac);
+      layer_scaling<NREG, NS>(L.lg, frac, dsc, rd);
+    }
+    lw_up_step<N>(src, Aab, Sab, crec, Abe, Sbe, dsc, rd);
     lw_overlap_above<URBAN, NREG, NS>(L, cu, jlay, nlay, Abe, Sbe, Aab, Sab);
   }
   lw_top<NREG, NS>(L, cidx, Aab, Sab);
@@ -264,7 +284,7 @@ SS_HD void layer_up_lw(const Launch& L, int cu) {
     }
     const FusedSource<LRec::SRC, Lds> src{&lds, hold};
     double Abe[N * N], Sbe[N];
-    lw_up_step<N>(src, Aab, Sab, crec, Abe, Sbe);
+    lw_up_step<N>(src, Aab, Sab, crec, Abe, Sbe, nullptr, nullptr);
   }
   if (nlay > 0) {
     const double* prev = L.col + rec_base(nlay - 1, L.maxlay, CRec::NELEM, cu);
@@ -323,11 +343,23 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
   constexpr int N = NREG * NS;
   constexpr int DB = URBAN ? NREG + 1 : NREG;
   constexpr int NB = DB * NS;
-  using LRec = LwRec<N>;
+  using LRec = LwLayRec<N>;
   using CRec = LwColRec<N>;
   constexpr long st = kRecStride;
   const Inputs& in = L.in;
   const LG& lg = L.lg;
+  // a_below of a layer from the column record: packed and scaled for the small orders (vf, bf: the layer's fractions)
+  auto load_abe = [&](const double* crec_, double vf_, double bf_, double* ABE_) {
+    if constexpr (CRec::PACKED) {
+      double frac_[NREG], dsc_[N], rd_[N];
+      region_fractions<URBAN, true, NREG>(vf_, bf_, frac_);
+      layer_scaling<NREG, NS>(lg, frac_, dsc_, rd_);
+      const RecSource src_{crec_, st};
+      load_packed_unscaled<N>(src_, CRec::ABE, dsc_, rd_, ABE_);
+    } else {
+      rec_load<N * N>(crec_, st, CRec::ABE, ABE_);
+    }
+  };
   const int col = L.cols[cu / L.nspec];
   const int jb = cu % L.nspec;
   const int nspec = L.nspec;
@@ -401,7 +433,7 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
     const double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
     double ABE[N * N], SBE[N];
     din.load_pack(pack_rec(L, jlay, cu, kPackLw));
-    rec_load<N * N>(crec, st, CRec::ABE, ABE);
+    load_abe(crec, din.g.veg_fraction, din.g.building_fraction, ABE);
     rec_load<N>(crec, st, CRec::SBE, SBE);
     SS_LOAD_FENCE();
     cross(din, true, 0.0, 0.0, ABE, SBE, dn_above, dn_below, up_below, nullptr);
@@ -436,7 +468,7 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
     if (jlay > 0) {
       const double* crec_n = L.col + rec_base(jlay - 1, L.maxlay, CRec::NELEM, cu);
       din.load_pack(pack_rec(L, jlay - 1, cu, kPackLw));
-      rec_load<N * N>(crec_n, st, CRec::ABE, ABE);
+      load_abe(crec_n, din.g.veg_fraction, din.g.building_fraction, ABE);
       rec_load<N>(crec_n, st, CRec::SBE, SBE);
     }
     SS_LOAD_FENCE();

@@ -29,7 +29,11 @@ struct SwColRec {
   static constexpr int PDN = 0;                           // P = Den^-1 T      N x N
   static constexpr int QDN = PDN + rec_even(N * N);       // Q = Den^-1 (R d_above E + S_dn)  N x D
   static constexpr int ABE = QDN + rec_even(N * D);       // a_below(l+1)      N x N (canopy part)
-  static constexpr int DBE = ABE + rec_even(N * N);       // d_below(l+1)      N x D (canopy part)
+  // a_below is symmetric in the scaled coordinates of its layer (reciprocity): the small orders store
+  // D^-1 a_below D as a packed lower triangle (sym_packed, ss_layer_matrices.hpp)
+  static constexpr bool PACKED = sym_packed(N, false);
+  static constexpr int NAB = PACKED ? tri_count(N) : N * N;
+  static constexpr int DBE = ABE + rec_even(NAB);         // d_below(l+1)      N x D (canopy part)
   // fused layer + upward kernel (fused_order(N)): no layer record exists, and what the downward
   // sweep reads of it travels in the column record: trans_dir_dir (E) and int_dir, D x D each
   static constexpr bool FUSED = fused_order(N, false);
@@ -102,15 +106,21 @@ SS_HD void sw_ground_albedo(const LG& lg, double ga, double gad, double cos_sza,
 // Adding step of one layer (forest :486-493, urban :619-626): consumes R, T, S_up, S_dn, E of
 // the layer from "src" (HBM layer record or the fused layer stage), stores the operators of
 // the downward sweep and a_below / d_below into the column record, returns the latter.
+// dsc, rd: scaling of the layer's components and its reciprocal (layer_scaling; read where the records are packed)
 template <int N, int D, class Src>
 SS_HD void sw_adding_step(const Src& src, const double* Aab, const double* Dab, double* crec,
-                          double* Abe, double* Dbe) {
-  using LRec = SwRec<N, D>;
+                          double* Abe, double* Dbe, const double* dsc, const double* rd) {
+  using LRec = SwLayRec<N, D>;
   using CRec = SwColRec<N, D>;
   constexpr long stride = kRecStride;
   double R[N * N], T[N * N], Den[N * N], X[N * N];
-  src.template load<N * N>(LRec::R, R);
-  src.template load<N * N>(LRec::T, T);
+  if constexpr (LRec::PACKED) {
+    load_packed_unscaled<N>(src, LRec::R, dsc, rd, R);
+    load_packed_unscaled<N>(src, LRec::T, dsc, rd, T);
+  } else {
+    src.template load<N * N>(LRec::R, R);
+    src.template load<N * N>(LRec::T, T);
+  }
   SS_LOAD_FENCE(); SS_SCHED_FENCE();   // the loads of E, S_dn, S_up stay where they are written (register pressure)
   // denominator = I - a_above R
   mat_mul<N, N, N>(Aab, R, Den);
@@ -129,7 +139,11 @@ SS_HD void sw_adding_step(const Src& src, const double* Aab, const double* Dab, 
   mat_mul<N, N, N>(T, X, Abe);
   SS_UNROLL_NN(N)
   for (int k = 0; k < N * N; ++k) Abe[k] = R[k] + Abe[k];
-  rec_store<N * N>(crec, stride, CRec::ABE, Abe);
+  if constexpr (CRec::PACKED) {
+    store_packed_scaled<N>(crec, stride, CRec::ABE, Abe, dsc, rd);
+  } else {
+    rec_store<N * N>(crec, stride, CRec::ABE, Abe);
+  }
   // d_below = S_up + T Den^-1 (d_above E + a_above S_dn)
   double E[D * D], S[N * D], Y[N * D];
   src.template load<D * D>(LRec::EDIR, E);
@@ -236,7 +250,7 @@ SS_HD void sw_top_albedos(const Launch& L, long cidx, double cos_sza, const doub
 template <bool URBAN, int NREG, int NS>
 SS_HD void column_up_sw(const Launch& L, int cu) {
   constexpr int N = NREG * NS, D = NREG;
-  using LRec = SwRec<N, D>;
+  using LRec = SwLayRec<N, D>;
   using CRec = SwColRec<N, D>;
   const Inputs& in = L.in;
   const SwColCtx<URBAN, NREG, NS> c(L, cu, false);
@@ -246,7 +260,14 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
     const RecSource src{L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu), kRecStride};
     double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
     double Abe[N * N], Dbe[N * D];
-    sw_adding_step<N, D>(src, Aab, Dab, crec, Abe, Dbe);
+    double dsc[N], rd[N];
+    if constexpr (LRec::PACKED || CRec::PACKED) {
+      double vf, bf, frac[NREG];
+      pack_fractions(pack_rec(L, jlay, cu, kPackSw), vf, bf);
+      region_fractions<URBAN, false, NREG>(vf, bf, frac);
+      layer_scaling<NREG, NS>(L.lg, frac, dsc, rd);
+    }
+    sw_adding_step<N, D>(src, Aab, Dab, crec, Abe, Dbe, dsc, rd);
     sw_overlap_above<URBAN, NREG, NS>(L, cu, jlay, c.nlay, c.cos_sza, Abe, Dbe, Aab, Dab);
   }
   sw_top_albedos<NREG, NS>(L, c.cidx, c.cos_sza, Aab, Dab);
@@ -296,7 +317,7 @@ SS_HD void layer_up_sw(const Launch& L, int cu) {
     const FusedSource<LRec::SUP, Lds> src{&lds, hold};
 #endif
     double Abe[N * N], Dbe[N * D];
-    sw_adding_step<N, D>(src, Aab, Dab, crec, Abe, Dbe);
+    sw_adding_step<N, D>(src, Aab, Dab, crec, Abe, Dbe, nullptr, nullptr);
   }
   if (c.nlay > 0) {
     const double* prev = L.col + rec_base(c.nlay - 1, L.maxlay, CRec::NELEM, cu);
@@ -386,12 +407,24 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
   constexpr int N = NREG * NS, D = NREG;
   constexpr int DB = URBAN ? NREG + 1 : NREG;
   constexpr int NB = DB * NS;
-  using LRec = SwRec<N, D>;
+  using LRec = SwLayRec<N, D>;
   using CRec = SwColRec<N, D>;
   constexpr long st = kRecStride;
   const Inputs& in = L.in;
   const LG& lg = L.lg;
   const SwColCtx<URBAN, NREG, NS> c(L, cu, true);
+  // a_below of a layer from the column record: packed and scaled for the small orders (vf, bf: the layer's fractions)
+  auto load_abe = [&](const double* crec_, double vf_, double bf_, double* ABE_) {
+    if constexpr (CRec::PACKED) {
+      double frac_[NREG], dsc_[N], rd_[N];
+      region_fractions<URBAN, false, NREG>(vf_, bf_, frac_);
+      layer_scaling<NREG, NS>(lg, frac_, dsc_, rd_);
+      const RecSource src_{crec_, st};
+      load_packed_unscaled<N>(src_, CRec::ABE, dsc_, rd_, ABE_);
+    } else {
+      rec_load<N * N>(crec_, st, CRec::ABE, ABE_);
+    }
+  };
   const int col = c.col, jb = c.jb, nspec = c.nspec, nlay = c.nlay, l0 = c.l0, itransp = c.itransp;
   const long cidx = c.cidx;
   const double cos_sza = c.cos_sza, sin0 = c.sin0;
@@ -479,7 +512,7 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
     const double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
     double ABE[N * N], DBE[N * D];
     din.load_pack(pack_rec(L, jlay, cu, kPackSw));
-    rec_load<N * N>(crec, st, CRec::ABE, ABE);
+    load_abe(crec, din.g.veg_fraction, din.g.building_fraction, ABE);
     rec_load<N * D>(crec, st, CRec::DBE, DBE);
     SS_LOAD_FENCE();
     const double lo[4] = {din.g.veg_fraction, din.g.building_fraction, din.roof_albedo, din.roof_albedo_dir};
@@ -548,7 +581,7 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
       const RecPair ra = rec_pair_load(pn + 8 * kRecStride);   // roof_albedo, roof_albedo_dir
       lo[2] = ra.x;
       lo[3] = ra.y;
-      rec_load<N * N>(crec_n, st, CRec::ABE, ABE);
+      load_abe(crec_n, lo[0], lo[1], ABE);
       rec_load<N * D>(crec_n, st, CRec::DBE, DBE);
     }
     if (CRec::FUSED) rec_load<D * D>(crec, st, CRec::IDIR, IDIR);

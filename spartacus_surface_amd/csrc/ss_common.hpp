@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cfloat>
+#include <type_traits>
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -67,6 +68,17 @@
 #endif
 
 namespace ss {
+
+// f(std::integral_constant<int, B>), ..., f(std::integral_constant<int, E - 1>): a loop whose index is a
+// compile-time constant in the body (packed-triangle index arithmetic must never reach the register allocator
+// as a run-time subscript: an array indexed that way is placed in scratch memory)
+template <int B, int E, class F>
+SS_HD void static_loop(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_loop<B + 1, E>(f);
+  }
+}
 
 // Per-lane staging space in LDS for the downward kernels: kLaneLdsSlots doubles
 // per lane, lane-interleaved (a wave's access to one slot is one conflict-free
@@ -134,6 +146,7 @@ struct LG {
   double hweight[kDevMaxStreams];
   double vweight[kDevMaxStreams];
   double sqrt_wmu[kDevMaxStreams];   // sqrt(weight * mu): stream part of the symmetrising scaling (ss_eigen_sym.hpp)
+  double rsqrt_wmu[kDevMaxStreams];  // its reciprocal
   double vadjustment;
   double vadjustment2;
 };

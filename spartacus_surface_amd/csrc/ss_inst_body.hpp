@@ -179,7 +179,7 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev, hipStream_t f
   {
     // the plan sized the scratch with its own formula: it must match the records
     constexpr int N = SS_INST_NREG * NS, D = SS_INST_NREG;
-    constexpr int lay_ne = fused_order(N, SS_INST_LW != 0) ? 0 : (SS_INST_LW ? LwRec<N>::NELEM : SwRec<N, D>::NELEM);
+    constexpr int lay_ne = fused_order(N, SS_INST_LW != 0) ? 0 : (SS_INST_LW ? LwLayRec<N>::NELEM : SwLayRec<N, D>::NELEM);
     constexpr int col_ne = SS_INST_LW ? LwColRec<N>::NELEM : SwColRec<N, D>::NELEM;
     if (L.lay_nelem != lay_ne || L.col_nelem != col_ne) return kLaunchBadRecord;
   }

@@ -69,6 +69,64 @@ struct LwRec {
   static constexpr int NELEM = ISRC + rec_even(NF);
 };
 
+// Layer records of the solver pipeline.  Orders whose layer matrices are computed in symmetrised coordinates
+// (3 <= NF <= SS_UNROLL_MAX: ss_layer_sym.hpp) store R^ = D^-1 R D and T^ = D^-1 T D - symmetric by
+// reciprocity - as packed lower triangles, NF (NF + 1) / 2 doubles instead of NF^2 (n = 6: the shortwave
+// record 128 -> 98 doubles, the longwave one 120 -> 90); the upward sweep restores R = D R^ D^-1 with the
+// scaling of its layer.  Every other order keeps the layout of SwRec / LwRec, which also remains the
+// layout of the general route (ss_layer_matrices.hpp, the kernel-level entries, the cold path).
+// Measured (C3, one stream, ms per step; tools/run_variants.sh): packing pays for the longwave (layer 3.29 ->
+// 3.12, upward sweep 3.11 -> 2.83, downward 2.58 -> 2.42) and costs in the shortwave, whose upward sweep is
+// short of registers (restoring R and T from 2 x 21 into 2 x 36 doubles next to a_above, d_above, S_up, S_dn:
+// 88 -> 121 spilled dwords, 3.81 -> 5.56 ms; the downward sweep 4.13 -> 4.41): the shortwave keeps full
+// records (-DSS_SYM_PACK_SW packs it too).
+constexpr bool sym_packed(int nf, bool lw) {
+#if defined(SS_NO_SYM_LAYER) || defined(SS_FUSE_SW) || defined(SS_FUSE_LW)
+  return false && nf > 0 && lw;
+#elif defined(SS_SYM_PACK_SW)
+  return nf >= 3 && nf <= SS_UNROLL_MAX && (lw || true);
+#else
+  return lw && nf >= 3 && nf <= SS_UNROLL_MAX;
+#endif
+}
+constexpr int tri_count(int n) { return n * (n + 1) / 2; }
+// packed lower triangle, column by column: index of (i, j), i >= j, and back
+constexpr int tri_index(int n, int i, int j) { return i + j * n - j * (j + 1) / 2; }
+constexpr int tri_col(int n, int e) {
+  int j = 0;
+  while (e >= n - j) { e -= n - j; ++j; }
+  return j;
+}
+constexpr int tri_row(int n, int e) {
+  int j = 0;
+  while (e >= n - j) { e -= n - j; ++j; }
+  return j + e;
+}
+
+template <int NF, int DF>
+struct SwLayRec {
+  static constexpr bool PACKED = sym_packed(NF, false);
+  static constexpr int NRT = PACKED ? tri_count(NF) : NF * NF;
+  static constexpr int R = 0;
+  static constexpr int T = R + rec_even(NRT);
+  static constexpr int SUP = T + rec_even(NRT);
+  static constexpr int SDN = SUP + rec_even(NF * DF);
+  static constexpr int EDIR = SDN + rec_even(NF * DF);
+  static constexpr int IDIR = EDIR + rec_even(DF * DF);
+  static constexpr int NELEM = IDIR + rec_even(DF * DF);
+};
+template <int NF>
+struct LwLayRec {
+  static constexpr bool PACKED = sym_packed(NF, true);
+  static constexpr int NRT = PACKED ? tri_count(NF) : NF * NF;
+  static constexpr int R = 0;
+  static constexpr int T = R + rec_even(NRT);
+  static constexpr int IFLUX = T + rec_even(NRT);
+  static constexpr int SRC = IFLUX + rec_even(NF * NF);
+  static constexpr int ISRC = SRC + rec_even(NF);
+  static constexpr int NELEM = ISRC + rec_even(NF);
+};
+
 // 16-byte element pair of the scratch
 #ifndef SS_RECPAIR_DEFINED
 #define SS_RECPAIR_DEFINED
@@ -181,12 +239,16 @@ struct ArrayRecWriter {
 // form costs nothing and takes 20 KB per column off the HBM traffic, so it is on; the
 // shortwave form stays available (-DSS_FUSE_SW) and correct (all parity tests pass with it).
 constexpr bool fused_order(int n, bool lw) {
-#if defined(SS_NO_FUSE)
-  return false && n > 0 && lw;
-#elif defined(SS_FUSE_SW)
+  // Round 3: with the layer matrices in symmetrised coordinates (ss_layer_sym.hpp) the layer kernel of the
+  // small orders no longer spills, and the three-kernel form is the faster one for the longwave too
+  // (measured, C3, ms per step on one stream: fused 7.06; layer 3.29 + upward 3.11).  The fused kernels
+  // remain for builds with -DSS_FUSE_LW / -DSS_FUSE_SW, which imply the full (unpacked) records.
+#if defined(SS_FUSE_SW)
   return n <= SS_UNROLL_MAX || (false && lw);
-#else
+#elif defined(SS_FUSE_LW)
   return lw && n <= SS_UNROLL_MAX && n < SS_COOP_MIN_ORDER;
+#else
+  return false && n > 0 && lw;
 #endif
 }
 
@@ -272,6 +334,70 @@ SS_HD void put_embedded_vec(const W& w, int off, F&& elem) {
   };
   SS_UNROLL_FULL
   for (int e = 0; e < NF; e += 2) w.put2(off + e, val(e), val(e + 1));
+}
+
+// Packed symmetric block of an N sub-problem at offset I0 into the packed NF record block at "off":
+// elem(ic, jc) with integral constants i >= j gives the sub-problem's element; everything else zero.
+template <int NF, int N, int I0, int E, typename F>
+SS_HD double packed_value(F&& elem) {
+  if constexpr (E >= tri_count(NF)) {
+    return 0.0;
+  } else {
+    constexpr int i = tri_row(NF, E), j = tri_col(NF, E);
+    if constexpr ((i >= I0) && (i < I0 + N) && (j >= I0) && (j < I0 + N))
+      return elem(std::integral_constant<int, i - I0>{}, std::integral_constant<int, j - I0>{});
+    else
+      return 0.0;
+  }
+}
+template <int NF, int N, int I0, class W, typename F>
+SS_HD void put_packed(const W& w, int off, F&& elem) {
+  static_loop<0, (tri_count(NF) + 1) / 2>([&](auto pc) {
+    constexpr int E = 2 * decltype(pc)::value;
+    w.put2(off + E, packed_value<NF, N, I0, E>(elem), packed_value<NF, N, I0, E + 1>(elem));
+  });
+}
+// Full N x N matrix from a packed scaled block of a record source: out(i, j) = dsc_i X^(i, j) / dsc_j
+template <int N, class Src>
+SS_HD void load_packed_unscaled(const Src& src, int off, const double* dsc, const double* rd, double* out) {
+  double t[rec_even(tri_count(N))];
+  src.template load<rec_even(tri_count(N))>(off, t);
+  static_loop<0, tri_count(N)>([&](auto ec) {
+    constexpr int E = decltype(ec)::value;
+    constexpr int i = tri_row(N, E), j = tri_col(N, E);
+    const double v = t[E];
+    SS_E(out, i, j, N) = (dsc[i] * rd[j]) * v;
+    if constexpr (i != j) SS_E(out, j, i, N) = (dsc[j] * rd[i]) * v;
+  });
+}
+// The lower triangle of D^-1 X D into a packed block of a record (X full, N x N)
+template <int N>
+SS_HD void store_packed_scaled(double* rec, long stride, int off, const double* X, const double* dsc, const double* rd) {
+  static_loop<0, (tri_count(N) + 1) / 2>([&](auto pc) {
+    constexpr int E = 2 * decltype(pc)::value;
+    constexpr int i0 = tri_row(N, E), j0 = tri_col(N, E);
+    double v1 = 0.0;
+    if constexpr (E + 1 < tri_count(N)) {
+      constexpr int i1 = tri_row(N, E + 1), j1 = tri_col(N, E + 1);
+      v1 = SS_E(X, i1, j1, N) * (dsc[j1] * rd[i1]);
+    }
+    rec_pair_store(rec + (long)(off + E) * stride, SS_E(X, i0, j0, N) * (dsc[j0] * rd[i0]), v1);
+  });
+}
+// scaling of the components of a layer: dsc = sqrt(region fraction) x sqrt(weight mu), rd = 1 / dsc
+// (0 for a region without area: its components carry no flux)
+template <int NREG, int NS>
+SS_HD void layer_scaling(const LG& lg, const double* frac, double* dsc, double* rd) {
+  SS_UNROLL_FULL
+  for (int r = 0; r < NREG; ++r) {
+    const double sf = sqrt(frac[r]);
+    const double rsf = frac[r] > 0.0 ? 1.0 / sf : 0.0;
+    SS_UNROLL_FULL
+    for (int s = 0; s < NS; ++s) {
+      dsc[s + r * NS] = sf * lg.sqrt_wmu[s];
+      rd[s + r * NS] = rsf * lg.rsqrt_wmu[s];
+    }
+  }
 }
 
 template <int N>
@@ -497,10 +623,9 @@ SS_HD int sw_direct_part(const double* g0, const double* dsc0, double dz, const 
 // int_dir_diff = -2 int_diff (g3 g0i) of the same routine are not formed: the downward sweep applies both
 // to its flux convergences with one solve with G1 + G2) and E = G0 diag(exp(mu dz)) G0^-1 (sw_eig :223-229).
 // Returns the eigen-solver's code; mu, G0, G0^-1 and exp(mu dz) for the particular solutions.
-template <int NF, int DF, int D, int R0, class W>
+template <int NF, int DF, int D, int R0, class Rec = SwRec<NF, DF>, class W>
 SS_HD int sw_direct_embedded(const double* g0, const double* dsc0, double dz, const W& w, double* mu, double* G0,
                              double* G0inv, double* emu) {
-  using Rec = SwRec<NF, DF>;
   SS_STAMP_DECL(w.stamps);
   {
     double LU0[D * D], g0i[D * D], idir[D * D];

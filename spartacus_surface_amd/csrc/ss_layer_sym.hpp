@@ -226,36 +226,53 @@ SS_HD double build_CM(const double* GD, const double* G2, const double* dscale, 
 //   sig (the eigenvalues sigma^2 of K, clamped at zero), A = L Y, Ainv_T = L^-T Y (= A^-T).
 // Returns 0, > 0 when the QL iteration did not converge, -1 when C is not positive definite or an
 // eigenvalue is not positive.
+// Spectral part shared by longwave and shortwave.  In: packed C (overwritten by its Cholesky factor L, rl =
+// 1 / diag L) and M.  Out: ev = the eigenvalues sigma^2 of K = L^T M L (Rayleigh quotients with M, clamped at
+// zero) and AiT = L^-T Y = A^-T (A = L Y is never stored: A x = C (A^-T x) = L (L^T (A^-T x))).
+// Returns 0, > 0 when the QL iteration did not converge, -1 when C is not positive definite or an
+// eigenvalue is negative beyond rounding.
 template <int N, class Lds>
-SS_HD int spectral(double* C, const double* M, double size, double* sig, double* A, double* AiT, const Lds& lds) {
-  double rl[N];
+SS_HD int spectral(double* C, double* rl, const double* M, double size, double* ev, double* AiT, const Lds& lds) {
   if (!cholesky<N>(C, rl, size)) return -1;
-  // K = L^T M L: W = M L (full), then the lower triangle of L^T W, mirrored (tred2 reads the lower one)
-  double K[N * N];
-  {
-    double Wm[N * N];
+  // K = L^T M L column by column: t = M L(:, j), K(i, j) = L(:, i)^T t for i >= j (tred2 reads the lower triangle)
+  double* K = AiT;      // the eigenvectors, then A^-T, replace K in place
+  SS_UNROLL_FULL
+  for (int j = 0; j < N; ++j) {
+    double t[N];
     SS_UNROLL_FULL
-    for (int j = 0; j < N; ++j) {
+    for (int i = 0; i < N; ++i) {
+      double s = 0.0;
       SS_UNROLL_FULL
-      for (int i = 0; i < N; ++i) {
-        double s = 0.0;
-        SS_UNROLL_FULL
-        for (int k = j; k < N; ++k) s += M[sy<N>(i, k)] * C[lo<N>(k, j)];
-        SS_E(Wm, i, j, N) = s;
-      }
+      for (int k = j; k < N; ++k) s += M[sy<N>(i, k)] * C[lo<N>(k, j)];
+      t[i] = s;
     }
     SS_UNROLL_FULL
-    for (int j = 0; j < N; ++j) {
+    for (int i = j; i < N; ++i) {
+      double s = 0.0;
       SS_UNROLL_FULL
-      for (int i = j; i < N; ++i) {
-        double s = 0.0;
-        SS_UNROLL_FULL
-        for (int k = i; k < N; ++k) s += C[lo<N>(k, i)] * SS_E(Wm, k, j, N);
-        SS_E(K, i, j, N) = s;
-        SS_E(K, j, i, N) = s;
-      }
+      for (int k = i; k < N; ++k) s += C[lo<N>(k, i)] * t[k];
+      SS_E(K, i, j, N) = s;
+      SS_E(K, j, i, N) = s;
     }
   }
+  int ierr = 0;
+  if constexpr (N == 1) {
+    ev[0] = K[0];
+    K[0] = 1.0;
+  } else if constexpr (N == 2) {
+    // one Jacobi rotation: exact eigenvectors of a symmetric 2 x 2 matrix
+    const double a = K[0], b = K[1], c = K[3];
+    double cs = 1.0, sn = 0.0, t = 0.0;
+    if (b != 0.0) {
+      const double zeta = (c - a) / (2.0 * b);
+      t = ss_sign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+      cs = 1.0 / sqrt(1.0 + t * t);
+      sn = cs * t;
+    }
+    ev[0] = a - t * b;
+    ev[1] = c + t * b;
+    K[0] = cs; K[1] = -sn; K[2] = sn; K[3] = cs;
+  } else {
   // Order of the components handed to the QL iteration: by ascending diagonal of K.  EISPACK's tred2 + tql2
   // keep the small eigenvalues AND their eigenvectors of a graded matrix accurate when its elements grow
   // towards the bottom right (measured on the transparent trunk layer of rami4pilps, eigenvalues over 13
@@ -282,9 +299,9 @@ SS_HD int spectral(double* C, const double* M, double size, double* sig, double*
   }
   SS_UNROLL_FULL
   for (int k = 0; k < N * N; ++k) K[k] = lds.get(k);
-  double ev[N], e[N];
+  double e[N];
   sym_tridiagonalise<N>(K, ev, e);
-  const int ierr = sym_tridiagonal_ql<N>(ev, e, K);
+  ierr = sym_tridiagonal_ql<N>(ev, e, K);
   // rows of the eigenvector matrix back into the solver's order
   SS_UNROLL_FULL
   for (int k = 0; k < N * N; ++k) lds.put(k, K[k]);
@@ -293,56 +310,65 @@ SS_HD int spectral(double* C, const double* M, double size, double* sig, double*
     SS_UNROLL_FULL
     for (int i = 0; i < N; ++i) SS_E(K, i, j, N) = lds.get(rank[i] + j * N);
   }
-  // sig receives the EIGENVALUES sigma^2.  The QL iteration has absolute accuracy eps * (largest eigenvalue):
-  // an eigenvalue far below that (transparent, conservative layers: 13 decades) may come out as rounding
-  // noise of either sign - harmless, because everything downstream depends on it through functions that
-  // are smooth at zero (phi, below); clamped.  A negative eigenvalue that is NOT noise declines the unit.
+  }
+  // The QL iteration has absolute accuracy eps * (largest eigenvalue): an eigenvalue far below that
+  // (transparent, conservative layers: 13 decades) may come out as rounding noise of either sign.  A negative
+  // eigenvalue that is NOT noise declines the unit.
   double evmax = 0.0;
   SS_UNROLL_FULL
   for (int j = 0; j < N; ++j) evmax = ss_max(evmax, ev[j]);
-  bool pos = true;
+  bool pos = evmax > 0.0;
   SS_UNROLL_FULL
-  for (int j = 0; j < N; ++j) {
+  for (int j = 0; j < N; ++j)
     if (!(ev[j] > -1.0e-10 * evmax)) pos = false;
-    sig[j] = ss_max(ev[j], 0.0);
-  }
-  if (!pos || !(evmax > 0.0)) return -1;
-  // A = L Y, A^-T = L^-T Y (back substitution with L^T), column by column
+  if (!pos) return -1;
+  // Column by column: y -> A^-T(:, j) = L^-T y (back substitution), and the eigenvalue as the Rayleigh quotient
+  // with M itself, sigma^2 = y^T K y = a^T M a with a = L y: the eigenvector error (~ eps x largest / gap)
+  // enters it squared, what is left is the rounding of M a, ~1e-17 absolute: eigenvalues 10 decades down keep
+  // 6-8 digits.  They carry the absorption of a nearly conservative layer (reflect_transmit) and meet mu^2 of
+  // the unattenuated direct mode in the particular solutions of the shortwave.
   SS_UNROLL_FULL
   for (int j = 0; j < N; ++j) {
+    double y[N], a[N], ma[N];
+    SS_UNROLL_FULL
+    for (int i = 0; i < N; ++i) y[i] = SS_E(K, i, j, N);
     SS_UNROLL_FULL
     for (int i = 0; i < N; ++i) {
       double s = 0.0;
       SS_UNROLL_FULL
-      for (int k = 0; k <= i; ++k) s += C[lo<N>(i, k)] * SS_E(K, k, j, N);
-      SS_E(A, i, j, N) = s;
+      for (int k = 0; k <= i; ++k) s += C[lo<N>(i, k)] * y[k];
+      a[i] = s;
     }
-    double v[N];
+    symv<N>(M, a, ma);
+    double rq = 0.0;
     SS_UNROLL_FULL
-    for (int i = 0; i < N; ++i) v[i] = SS_E(K, i, j, N);
-    solve_LT<N>(C, rl, v);
+    for (int i = 0; i < N; ++i) rq += a[i] * ma[i];
+    ev[j] = ss_max(rq, 0.0);
+    solve_LT<N>(C, rl, y);
     SS_UNROLL_FULL
-    for (int i = 0; i < N; ++i) SS_E(AiT, i, j, N) = v[i];
-#if !defined(SS_SYM_NO_RAYLEIGH)
-    // Eigenvalue as the Rayleigh quotient with M itself: sigma^2 = y^T K y = (L y)^T M (L y).  The QL
-    // iteration returns an eigenvalue with the absolute accuracy eps x (largest eigenvalue), the eigenvector
-    // with an error ~ eps x largest / gap that enters the quotient squared; what is left is the rounding of
-    // M a, ~1e-17 absolute: eigenvalues 10 decades down keep 6-8 digits.  They carry the absorption of a
-    // nearly conservative layer (see reflect_transmit) and meet mu^2 of the unattenuated direct mode in
-    // the particular solutions of the shortwave.
-    {
-      double ma[N];
-      SS_UNROLL_FULL
-      for (int i = 0; i < N; ++i) v[i] = SS_E(A, i, j, N);
-      symv<N>(M, v, ma);
-      double rq = 0.0;
-      SS_UNROLL_FULL
-      for (int i = 0; i < N; ++i) rq += v[i] * ma[i];
-      sig[j] = ss_max(rq, 0.0);
-    }
-#endif
+    for (int i = 0; i < N; ++i) SS_E(AiT, i, j, N) = y[i];
   }
   return ierr;
+}
+
+// x := C x = L (L^T x) with the packed Cholesky factor
+template <int N>
+SS_HD void apply_C(const double* L, double* x) {
+  double t[N];
+  SS_UNROLL_FULL
+  for (int k = 0; k < N; ++k) {
+    double s = 0.0;
+    SS_UNROLL_FULL
+    for (int i = k; i < N; ++i) s += L[lo<N>(i, k)] * x[i];
+    t[k] = s;
+  }
+  SS_UNROLL_FULL
+  for (int i = 0; i < N; ++i) {
+    double s = 0.0;
+    SS_UNROLL_FULL
+    for (int k = 0; k <= i; ++k) s += L[lo<N>(i, k)] * t[k];
+    x[i] = s;
+  }
 }
 
 // phi(x) = tanh(x) / x for x >= 0: smooth, in (0, 1], phi(0) = 1
@@ -353,72 +379,91 @@ SS_HD double phi_tanh(double x) {
   return -em1 / ((2.0 + em1) * x);
 }
 
-// Scaled reflectance and transmittance (packed symmetric) of a layer of half-thickness h, W+, and
-//   Phi = L (tanh(kappa h) / kappa) L^-1 = A diag(h phi(sigma h)) A^-1   (full, N x N).
-// The impedances are formed as
-//   Z+ = M Phi          (= L^-T kappa tanh(kappa h) L^-1, since M L = L^-T K)
+// The two impedances of a layer of half-thickness h and their Cayley transforms W+- = (I + Z+-)^-1 (packed):
 //   Z- = A^-T diag(1 / (h phi)) A^-1
-// so that an eigenvalue enters only through phi, which is smooth at zero.  This matters: the absorption of
-// a layer is 1 - R - T = 2 Z+ W+, and for a nearly conservative layer (clear air: extinction 1e-5, single-
-// scattering albedo 0.999) it lives in eigenvalues 13 decades below the largest one, which a QL iteration
-// delivers with NO correct digit.  Z+ = A^-T diag(sigma tanh(sigma h)) A^-1 inherits that error (measured:
-// layer absorption off by 1e-3, or 1e-4 ... 1e-6 with other index orders handed to the QL iteration);
-// M Phi takes the small numbers from M - input data - and only a smooth factor from the eigen-decomposition
-// (8e-7 whatever the order; LAPACK dsyevd and one-sided Jacobi in the old form: 6e-7; the reference: 2e-5).
-template <int N>
-SS_HD void reflect_transmit(const double* M, const double* A, const double* AiT, const double* ev, double h,
-                            double* Rh, double* Th, double* Wp, double* Phi) {
+//   Z+ = M Phi,  Phi = C Psi,  Psi = A^-T diag(h phi) A^-1 = L^-T (tanh(kappa h) / kappa) L^-1 (symmetric)
+// (Z+ = L^-T kappa tanh(kappa h) L^-1, since M L = L^-T K).  An eigenvalue enters only through phi(sigma h),
+// smooth at zero.  This matters: the absorption of a layer is 1 - R - T = 2 Z+ W+, and for a nearly
+// conservative layer (clear air: extinction 1e-5, single-scattering albedo 0.999) it lives in eigenvalues 13
+// decades below the largest one, which a QL iteration delivers with NO correct digit.  Z+ in its spectral form
+// A^-T diag(sigma tanh(sigma h)) A^-1 inherits that error (measured: layer absorption off by 1e-3 ... 1e-6
+// depending on the index order handed to the QL iteration); M Phi takes the small numbers from M - input
+// data - and only a smooth factor from the eigen-decomposition (2e-7 whatever the order; LAPACK dsyevd and
+// one-sided Jacobi in the spectral form: 6e-7; the reference: 2e-5).
+// KEEP_PHI: Phi (full, N x N) is returned (longwave: integrated flux = 2 Phi W+); else Phi may be nullptr.
+template <int N, bool KEEP_PHI>
+SS_HD void impedances(const double* M, const double* L, const double* AiT, const double* ev, double h,
+                      double* Wp, double* Wm, double* Phi) {
   double t[N], fm[N];
   SS_UNROLL_FULL
   for (int k = 0; k < N; ++k) {
-    const double ph = phi_tanh(sqrt(ev[k]) * h);
-    t[k] = h * ph;
+    t[k] = h * phi_tanh(sqrt(ev[k]) * h);
     fm[k] = 1.0 / t[k];
   }
-  // Phi(i, j) = sum_k A(i,k) t_k AiT(j,k)
+  rank_update<N>(AiT, fm, Wm);
+  inverse_of_identity_plus<N>(Wm);
+  double Psi[kTri<N>];
+  rank_update<N>(AiT, t, Psi);
+  // column j of Phi = C Psi(:, j); Z+(i, j) = M(i, :) Phi(:, j) for i >= j (symmetric in exact arithmetic)
   SS_UNROLL_FULL
   for (int j = 0; j < N; ++j) {
-    double at[N];
+    double c[N];
     SS_UNROLL_FULL
-    for (int k = 0; k < N; ++k) at[k] = t[k] * SS_E(AiT, j, k, N);
-    SS_UNROLL_FULL
-    for (int i = 0; i < N; ++i) {
-      double s = 0.0;
+    for (int i = 0; i < N; ++i) c[i] = Psi[sy<N>(i, j)];
+    apply_C<N>(L, c);
+    if constexpr (KEEP_PHI) {
       SS_UNROLL_FULL
-      for (int k = 0; k < N; ++k) s += SS_E(A, i, k, N) * at[k];
-      SS_E(Phi, i, j, N) = s;
+      for (int i = 0; i < N; ++i) SS_E(Phi, i, j, N) = c[i];
     }
-  }
-  // Z+ = M Phi (lower triangle; symmetric in exact arithmetic), W+ = (I + Z+)^-1
-  SS_UNROLL_FULL
-  for (int j = 0; j < N; ++j) {
     SS_UNROLL_FULL
     for (int i = j; i < N; ++i) {
       double s = 0.0;
       SS_UNROLL_FULL
-      for (int k = 0; k < N; ++k) s += M[sy<N>(i, k)] * SS_E(Phi, k, j, N);
+      for (int k = 0; k < N; ++k) s += M[sy<N>(i, k)] * c[k];
       Wp[lo<N>(i, j)] = s;
     }
   }
   inverse_of_identity_plus<N>(Wp);
-  double Wm[kTri<N>];
-  rank_update<N>(AiT, fm, Wm);
-  inverse_of_identity_plus<N>(Wm);
-  SS_UNROLL_FULL
-  for (int k = 0; k < kTri<N>; ++k) {
-    Rh[k] = Wp[k] + Wm[k];
-    Th[k] = Wp[k] - Wm[k];
+}
+
+// R^ = W+ + W- - I and T^ = W+ - W- into the record: packed and scaled where the record is
+// (SwLayRec / LwLayRec, ss_layer_matrices.hpp), else un-scaled (R = D R^ D^-1) into the full blocks
+template <int NF, int N, int I0, bool PACKED, class W>
+SS_HD void put_reflect_transmit(const W& w, int offR, int offT, const double* Wp, const double* Wm,
+                                const double* dsc, const double* rd) {
+  if constexpr (PACKED) {
+    put_packed<NF, N, I0>(w, offR, [&](auto ic, auto jc) {
+      constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+      return Wp[lo<N>(i, j)] + Wm[lo<N>(i, j)] - (i == j ? 1.0 : 0.0);
+    });
+    put_packed<NF, N, I0>(w, offT, [&](auto ic, auto jc) {
+      constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+      return Wp[lo<N>(i, j)] - Wm[lo<N>(i, j)];
+    });
+  } else {
+    double t[N * N];
+    SS_UNROLL_FULL
+    for (int j = 0; j < N; ++j) {
+      SS_UNROLL_FULL
+      for (int i = 0; i < N; ++i)
+        SS_E(t, i, j, N) = (dsc[i] * rd[j]) * (Wp[sy<N>(i, j)] + Wm[sy<N>(i, j)] - (i == j ? 1.0 : 0.0));
+    }
+    put_embedded<NF, NF, N, N, I0, I0>(w, offR, t);
+    SS_UNROLL_FULL
+    for (int j = 0; j < N; ++j) {
+      SS_UNROLL_FULL
+      for (int i = 0; i < N; ++i) SS_E(t, i, j, N) = (dsc[i] * rd[j]) * (Wp[sy<N>(i, j)] - Wm[sy<N>(i, j)]);
+    }
+    put_embedded<NF, NF, N, N, I0, I0>(w, offT, t);
   }
-  SS_UNROLL_FULL
-  for (int j = 0; j < N; ++j) Rh[lo<N>(j, j)] -= 1.0;
 }
 
 // calc_matrices_lw_eig in symmetrised coordinates for an N sub-problem embedded at stream offset I0 of
-// the (NF x NF) record; same outputs, same (unscaled) record layout as calc_matrices_lw.
+// the (NF x NF) record; same outputs as calc_matrices_lw, in the layout of the pipeline's layer record.
 template <int NF, int N, int I0, class W, class Lds>
 SS_HD int calc_matrices_lw_sym(const double* g1, const double* g2, const double* b, const double* dsc, double dz,
                                const W& w, const Lds& lds) {
-  using Rec = LwRec<NF>;
+  using Rec = LwLayRec<NF>;
   double C[kTri<N>], M[kTri<N>], size;
   {
     double GD[N * N];
@@ -427,7 +472,7 @@ SS_HD int calc_matrices_lw_sym(const double* g1, const double* g2, const double*
     size = build_CM<N>(GD, g2, dsc, C, M);
   }
   if (!(size > 0.0)) return -1;
-  // particular solution g^ = M^-1 b^ (Cholesky of a copy of M: M itself is needed for K)
+  // particular solution g^ = M^-1 b^ (Cholesky of a copy of M: M itself is needed later)
   double gh[N];
   {
     double F[kTri<N>], rf[N];
@@ -439,29 +484,15 @@ SS_HD int calc_matrices_lw_sym(const double* g1, const double* g2, const double*
     solve_L<N>(F, rf, gh);
     solve_LT<N>(F, rf, gh);
   }
-  double sig[N], A[N * N], AiT[N * N];
-  const int ierr = spectral<N>(C, M, size, sig, A, AiT, lds);
+  double ev[N], rl[N], AiT[N * N];
+  const int ierr = spectral<N>(C, rl, M, size, ev, AiT, lds);
   if (ierr < 0) return -1;
-  double Rh[kTri<N>], Th[kTri<N>], Wp[kTri<N>], Phi[N * N];
-  reflect_transmit<N>(M, A, AiT, sig, 0.5 * dz, Rh, Th, Wp, Phi);
+  double Wp[kTri<N>], Wm[kTri<N>], Phi[N * N];
+  impedances<N, true>(M, C, AiT, ev, 0.5 * dz, Wp, Wm, Phi);
   double rd[N];
   SS_UNROLL_FULL
   for (int i = 0; i < N; ++i) rd[i] = 1.0 / dsc[i];
-  {
-    double t[N * N];
-    SS_UNROLL_FULL
-    for (int j = 0; j < N; ++j) {
-      SS_UNROLL_FULL
-      for (int i = 0; i < N; ++i) SS_E(t, i, j, N) = (dsc[i] * rd[j]) * Rh[sy<N>(i, j)];
-    }
-    put_embedded<NF, NF, N, N, I0, I0>(w, Rec::R, t);
-    SS_UNROLL_FULL
-    for (int j = 0; j < N; ++j) {
-      SS_UNROLL_FULL
-      for (int i = 0; i < N; ++i) SS_E(t, i, j, N) = (dsc[i] * rd[j]) * Th[sy<N>(i, j)];
-    }
-    put_embedded<NF, NF, N, N, I0, I0>(w, Rec::T, t);
-  }
+  put_reflect_transmit<NF, N, I0, Rec::PACKED>(w, Rec::R, Rec::T, Wp, Wm, dsc, rd);
   // source = 2 Z+ W+ g^ = 2 M (Phi (W+ g^)): the small numbers come from M
   double y[N], py[N], srch[N];
   symv<N>(Wp, gh, y);
@@ -488,14 +519,15 @@ SS_HD int calc_matrices_lw_sym(const double* g1, const double* g2, const double*
 }
 
 // calc_matrices_sw_eig in symmetrised coordinates for an (N, D) sub-problem embedded at (I0, R0) of the
-// (NF, DF) record; same outputs and record layout as calc_matrices_sw.  The direct-beam part (Gamma0: D x D)
+// (NF, DF) record; same outputs as calc_matrices_sw, in the layout of the pipeline's layer record (the blocks
+// behind R and T sit at the same distances as in SwRec).  The direct-beam part (Gamma0: D x D)
 // is shared with the general route (sw_direct_embedded); the direct-diffuse part, a (2n + d) square system
-// in the reference (direct_diffuse_part, sw_eig :303-386), is four symmetric matrix-vector products per
+// in the reference (direct_diffuse_part, sw_eig :303-386), is two symmetric matrix-vector products per
 // direct eigenvalue here.
 template <int NF, int DF, int N, int D, int I0, int R0, class W, class Lds>
 SS_HD int calc_matrices_sw_sym(const double* g0, const double* g1, const double* g2, const double* g3,
                                const double* dsc0, const double* dsc, double dz, const W& w, const Lds& lds) {
-  using Rec = SwRec<NF, DF>;
+  using Rec = SwLayRec<NF, DF>;
   double C[kTri<N>], M[kTri<N>], size;
   {
     double GD[N * N];
@@ -504,41 +536,22 @@ SS_HD int calc_matrices_sw_sym(const double* g0, const double* g1, const double*
     size = build_CM<N>(GD, g2, dsc, C, M);
   }
   if (!(size > 0.0)) return -1;
-  double sig[N], A[N * N], AiT[N * N];
-  int ierr = spectral<N>(C, M, size, sig, A, AiT, lds);
+  double ev[N], rl[N], AiT[N * N];
+  int ierr = spectral<N>(C, rl, M, size, ev, AiT, lds);
   if (ierr < 0) return -1;
 
   double mu[D], G0[D * D], G0inv[D * D], emu[D];
-  ierr += sw_direct_embedded<NF, DF, D, R0>(g0, dsc0, dz, w, mu, G0, G0inv, emu);
-
-  double Rh[kTri<N>], Th[kTri<N>];
-  {
-    double Wp[kTri<N>], Phi[N * N];
-    reflect_transmit<N>(M, A, AiT, sig, 0.5 * dz, Rh, Th, Wp, Phi);
-  }
+  ierr += sw_direct_embedded<NF, DF, D, R0, Rec>(g0, dsc0, dz, w, mu, G0, G0inv, emu);
   double rd[N];
   SS_UNROLL_FULL
   for (int i = 0; i < N; ++i) rd[i] = 1.0 / dsc[i];
-  {
-    double t[N * N];
-    SS_UNROLL_FULL
-    for (int j = 0; j < N; ++j) {
-      SS_UNROLL_FULL
-      for (int i = 0; i < N; ++i) SS_E(t, i, j, N) = (dsc[i] * rd[j]) * Rh[sy<N>(i, j)];
-    }
-    put_embedded<NF, NF, N, N, I0, I0>(w, Rec::R, t);
-    SS_UNROLL_FULL
-    for (int j = 0; j < N; ++j) {
-      SS_UNROLL_FULL
-      for (int i = 0; i < N; ++i) SS_E(t, i, j, N) = (dsc[i] * rd[j]) * Th[sy<N>(i, j)];
-    }
-    put_embedded<NF, NF, N, N, I0, I0>(w, Rec::T, t);
-  }
-  // Particular solutions of the direct sources (sw_eig :231-253), one per direct eigenvalue mu, scaled:
-  //   p^ = g3^ + g4^ = A c,  q^ = g3^ - g4^ = mu A^-T c,  c = (sigma^2 - mu^2)^-1 A^T 2 s^,  s^ = D^-1 (Gamma3 G0)(:, jd)
-  // (the eigenvalues sigma^2 are the Rayleigh quotients with M of spectral(): in a transparent layer the
-  // unattenuated direct mode, mu^2 ~ 1e-10, meets eigenvalues of the same size in this division)
-  double su[N * D], sd[N * D];
+
+  // Particular solutions of the direct sources (sw_eig :231-253), one per direct eigenvalue mu, scaled: with
+  // s^ = D^-1 (Gamma3 G0)(:, jd), p^ = g3^ + g4^ and q^ = g3^ - g4^ obey (C M - mu^2) p^ = 2 C s^, q^ = mu C^-1 p^:
+  //     p^ = C r,  q^ = mu r,  r = A^-T (sigma^2 - mu^2)^-1 A^-1 C 2 s^
+  // (the eigenvalues are the Rayleigh quotients of spectral(): in a transparent layer the unattenuated direct
+  // mode, mu^2 ~ 1e-10, meets eigenvalues of the same size in this division).  Kept: r (N per mode).
+  double rv[N * D];
   SS_UNROLL_FULL
   for (int jd = 0; jd < D; ++jd) {
     double sh[N];
@@ -549,39 +562,51 @@ SS_HD int calc_matrices_sw_sym(const double* g0, const double* g1, const double*
       for (int k = 0; k < D; ++k) t += SS_E(g3, i, k, N) * SS_E(G0, k, jd, D);
       sh[i] = 2.0 * t * rd[i];
     }
+    apply_C<N>(C, sh);
     double c[N];
     SS_UNROLL_FULL
     for (int k = 0; k < N; ++k) {
       double t = 0.0;
       SS_UNROLL_FULL
-      for (int i = 0; i < N; ++i) t += SS_E(A, i, k, N) * sh[i];
-      c[k] = t / (sig[k] - mu[jd] * mu[jd]);       // sig = sigma^2
+      for (int i = 0; i < N; ++i) t += SS_E(AiT, i, k, N) * sh[i];
+      c[k] = t / (ev[k] - mu[jd] * mu[jd]);
     }
-    double g3h[N], g4h[N];
     SS_UNROLL_FULL
     for (int i = 0; i < N; ++i) {
-      double pv = 0.0, qv = 0.0;
+      double s = 0.0;
       SS_UNROLL_FULL
-      for (int k = 0; k < N; ++k) {
-        pv += SS_E(A, i, k, N) * c[k];
-        qv += SS_E(AiT, i, k, N) * c[k];
-      }
-      qv *= mu[jd];
-      g3h[i] = 0.5 * (pv + qv);
-      g4h[i] = 0.5 * (pv - qv);
+      for (int k = 0; k < N; ++k) s += SS_E(AiT, i, k, N) * c[k];
+      SS_E(rv, i, jd, N) = s;
     }
-    // S_up = g3 - R g4 - T g3 e,  S_dn = g4 e - T g4 - R g3 e   (e = exp(mu dz))
-    double g3e[N], r4[N], t3[N], t4[N], r3[N];
+  }
+  double Wp[kTri<N>], Wm[kTri<N>];
+  impedances<N, false>(M, C, AiT, ev, 0.5 * dz, Wp, Wm, nullptr);
+  put_reflect_transmit<NF, N, I0, Rec::PACKED>(w, Rec::R, Rec::T, Wp, Wm, dsc, rd);
+  // The fluxes that leave the layer per unit amplitude of a direct mode: with g3 = (p + q) / 2, g4 = (p - q) / 2,
+  // e = exp(mu dz), R^ = W+ + W- - I, T^ = W+ - W-:
+  //   S_up = g3 - R g4 - T g3 e = p - W+ x+ - W- x-,   S_dn = g4 e - T g4 - R g3 e = e p - W+ x+ + W- x-,
+  //   x+ = g4 + g3 e,  x- = g4 - g3 e
+  double su[N * D], sd[N * D];
+  SS_UNROLL_FULL
+  for (int jd = 0; jd < D; ++jd) {
+    double p[N], xp[N], xm[N], wp[N], wm[N];
     SS_UNROLL_FULL
-    for (int i = 0; i < N; ++i) g3e[i] = g3h[i] * emu[jd];
-    symv<N>(Rh, g4h, r4);
-    symv<N>(Th, g3e, t3);
-    symv<N>(Th, g4h, t4);
-    symv<N>(Rh, g3e, r3);
+    for (int i = 0; i < N; ++i) p[i] = SS_E(rv, i, jd, N);
+    apply_C<N>(C, p);
+    const double e = emu[jd];
     SS_UNROLL_FULL
     for (int i = 0; i < N; ++i) {
-      SS_E(su, i, jd, N) = dsc[i] * (g3h[i] - r4[i] - t3[i]);
-      SS_E(sd, i, jd, N) = dsc[i] * (g4h[i] * emu[jd] - t4[i] - r3[i]);
+      const double q = mu[jd] * SS_E(rv, i, jd, N);
+      const double g3h = 0.5 * (p[i] + q), g4h = 0.5 * (p[i] - q);
+      xp[i] = g4h + g3h * e;
+      xm[i] = g4h - g3h * e;
+    }
+    symv<N>(Wp, xp, wp);
+    symv<N>(Wm, xm, wm);
+    SS_UNROLL_FULL
+    for (int i = 0; i < N; ++i) {
+      SS_E(su, i, jd, N) = dsc[i] * (p[i] - wp[i] - wm[i]);
+      SS_E(sd, i, jd, N) = dsc[i] * (e * p[i] - wp[i] + wm[i]);
     }
   }
   {

@@ -78,13 +78,17 @@ inline int lay_nelem(bool lw, const ClassKey& k) {
   const int n = k.nreg * k.ns, d = k.nreg;
   if (fused_order(n, lw)) return 0;
   auto ev = [](int x) { return (x + 1) & ~1; };   // blocks start at even elements (16-byte pairs)
-  return lw ? 3 * ev(n * n) + 2 * ev(n) : 2 * ev(n * n) + 2 * ev(n * d) + 2 * ev(d * d);
+  // = LwLayRec<n>::NELEM / SwLayRec<n, d>::NELEM (ss_layer_matrices.hpp): R^ and T^ packed for the small orders
+  const int rt = sym_packed(n, lw) ? tri_count(n) : n * n;
+  return lw ? 2 * ev(rt) + ev(n * n) + 2 * ev(n) : 2 * ev(rt) + 2 * ev(n * d) + 2 * ev(d * d);
 }
 inline int col_nelem(bool lw, const ClassKey& k) {
   const int n = k.nreg * k.ns, d = k.nreg;
   // = LwColRec<n>::NELEM / SwColRec<n,d>::NELEM (ss_column_lw.hpp, ss_column_sw.hpp)
   auto ev = [](int x) { return (x + 1) & ~1; };
-  const int base = lw ? 2 * ev(n * n) + 2 * ev(n) : 2 * ev(n * n) + 2 * ev(n * d);
+  // a_below is packed (scaled, symmetric) for the small orders
+  const int ab = sym_packed(n, lw) ? tri_count(n) : n * n;
+  const int base = lw ? ev(n * n) + ev(ab) + 2 * ev(n) : ev(n * n) + ev(ab) + 2 * ev(n * d);
   if (!fused_order(n, lw)) return base;
 #if defined(SS_FUSE_VIA_RECORD)
   return base + (lw ? ev(n * n) + ev(n) : 2 * ev(d * d) + 2 * ev(n * d));
@@ -630,6 +634,7 @@ class Plan {
       l.hweight[i] = on ? g.hweight[i] : 0.0;
       l.vweight[i] = on ? g.vweight[i] : 0.0;
       l.sqrt_wmu[i] = on ? std::sqrt(g.weight[i] * g.mu[i]) : 1.0;
+      l.rsqrt_wmu[i] = 1.0 / l.sqrt_wmu[i];
     }
     l.vadjustment = g.vadjustment;
     l.vadjustment2 = g.vadjustment2;

@@ -239,7 +239,7 @@ template <int NF, int N, int I0, bool GENERAL, class W>
 SS_HD int calc_matrices_lw_route(const double* g1, const double* g2, const double* b, const double* dsc, double dz,
                                  const W& w, const CoopEig* coop = nullptr) {
 #if !defined(SS_NO_SYM_LAYER)
-  if constexpr (!GENERAL && N >= 3 && N <= SS_UNROLL_MAX) {
+  if constexpr (!GENERAL && NF >= 3 && N <= SS_UNROLL_MAX) {
     int rc = -1;
     if (dsc) rc = sym::calc_matrices_lw_sym<NF, N, I0>(g1, g2, b, dsc, dz, w, w.scratch());
     // sub-problems of the orders above SS_UNROLL_MAX (second pass of the layer kernel, itself the slow
@@ -251,7 +251,7 @@ SS_HD int calc_matrices_lw_route(const double* g1, const double* g2, const doubl
 }
 
 template <bool URBAN, int NREG, int NS>
-SS_HD_NOINLINE void layer_unit_lw_cold(const Launch& L, int cu, int jlay, double* rec);
+SS_HD_NOINLINE void layer_unit_lw_cold(const Launch* Lp, int cu, int jlay, double* rec);
 
 // W: RecWriter (HBM layer record) or the FusedWriter of k_layer_up (ss_layer_matrices.hpp)
 // (STAGE: see layer_unit_sw)
@@ -430,11 +430,36 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
     if (ierr < 0) {
       // declined by the symmetrised route (nothing written yet): the whole unit again, general route, out of
       // line - the cold path must not keep the Gamma matrices of this path alive, nor set its register budget
-      double rec[LwRec<N>::NELEM];
-      for (int k = 0; k < LwRec<N>::NELEM; ++k) rec[k] = 0.0;
-      layer_unit_lw_cold<URBAN, NREG, NS>(L, cu, jlay, rec);
-      SS_UNROLL_FULL
-      for (int e = 0; e < LwRec<N>::NELEM; e += 2) w.put2(e, rec[e], rec[e + 1]);
+      using FRec = LwRec<N>;          // what the general route writes
+      using LRec = LwLayRec<N>;       // what the pipeline reads
+      double rec[FRec::NELEM];
+      for (int k = 0; k < FRec::NELEM; ++k) rec[k] = 0.0;
+      // (device: the cold unit finds the launch descriptor in the kernel-argument segment itself; handing it
+      // &L would make every wave copy the descriptor - 800 bytes per lane - to scratch at kernel entry)
+#if defined(__HIP_DEVICE_COMPILE__)
+      layer_unit_lw_cold<URBAN, NREG, NS>(nullptr, cu, jlay, rec);
+#else
+      layer_unit_lw_cold<URBAN, NREG, NS>(&L, cu, jlay, rec);
+#endif
+      if constexpr (LRec::PACKED) {
+        // R^ = D^-1 R D, T^ likewise: lower triangles (reciprocity makes them symmetric)
+        double rdv[N];
+        for (int i = 0; i < N; ++i) rdv[i] = dsc[i] > 0.0 ? 1.0 / dsc[i] : 0.0;
+        put_packed<N, N, 0>(w, LRec::R, [&](auto ic, auto jc) {
+          constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+          return rec[FRec::R + i + j * N] * (dsc[j] * rdv[i]);
+        });
+        put_packed<N, N, 0>(w, LRec::T, [&](auto ic, auto jc) {
+          constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+          return rec[FRec::T + i + j * N] * (dsc[j] * rdv[i]);
+        });
+        SS_UNROLL_FULL
+        for (int e = 0; e < FRec::NELEM - FRec::IFLUX; e += 2)
+          w.put2(LRec::IFLUX + e, rec[FRec::IFLUX + e], rec[FRec::IFLUX + e + 1]);
+      } else {
+        SS_UNROLL_FULL
+        for (int e = 0; e < FRec::NELEM; e += 2) w.put2(e, rec[e], rec[e + 1]);
+      }
       return;
     }
   }
@@ -446,14 +471,21 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
 }
 
 template <bool URBAN, int NREG, int NS>
-SS_HD_NOINLINE void layer_unit_lw_cold(const Launch& L, int cu, int jlay, double* rec) {
+SS_HD_NOINLINE void layer_unit_lw_cold(const Launch* Lp, int cu, int jlay, double* rec) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // every kernel that reaches this unit takes the launch descriptor as its only argument, by value
+  (void)Lp;
+  const Launch& L = *(const Launch*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+  const Launch& L = *Lp;
+#endif
   const ArrayRecWriter w{rec, nullptr};
   layer_unit_lw<URBAN, NREG, NS, ArrayRecWriter, 0, true>(L, cu, jlay, w);
 }
 
 template <bool URBAN, int NREG, int NS, int STAGE = 0>
 SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay) {
-  using Rec = LwRec<NREG * NS>;
+  using Rec = LwLayRec<NREG * NS>;
   const RecWriter w{L.lay + rec_base(jlay, L.maxlay, Rec::NELEM, cu), kRecStride, (unsigned long long*)L.eigen_fail};
   layer_unit_lw<URBAN, NREG, NS, RecWriter, STAGE>(L, cu, jlay, w);
 }

@@ -168,7 +168,7 @@ SS_HD int calc_matrices_sw_route(const double* g0, const double* g1, const doubl
                                  const double* dsc0, const double* dsc, double dz, const W& w,
                                  const CoopEig* coop = nullptr) {
 #if !defined(SS_NO_SYM_LAYER)
-  if constexpr (!GENERAL && N >= 3 && N <= SS_UNROLL_MAX) {
+  if constexpr (!GENERAL && NF >= 3 && N <= SS_UNROLL_MAX) {
     int rc = -1;
     if (dsc) rc = sym::calc_matrices_sw_sym<NF, DF, N, D, I0, R0>(g0, g1, g2, g3, dsc0, dsc, dz, w, w.scratch());
     if (rc >= 0 || NF <= SS_UNROLL_MAX) return rc;      // (see calc_matrices_lw_route)
@@ -178,7 +178,7 @@ SS_HD int calc_matrices_sw_route(const double* g0, const double* g1, const doubl
 }
 
 template <bool URBAN, int NREG, int NS>
-SS_HD_NOINLINE void layer_unit_sw_cold(const Launch& L, int cu, int jlay, double* rec);
+SS_HD_NOINLINE void layer_unit_sw_cold(const Launch* Lp, int cu, int jlay, double* rec);
 
 // First pass of the layer kernel for the orders the row-of-16 kernels take (see layer_first_lw)
 template <bool URBAN, int NREG, int NS, class W>
@@ -505,11 +505,36 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
   if constexpr (!GENERAL && STAGE == 0 && N <= SS_UNROLL_MAX) {
     if (ierr < 0) {
       // declined by the symmetrised route (nothing written yet): the whole unit again, out of line
-      double rec[SwRec<N, D>::NELEM];
-      for (int k = 0; k < SwRec<N, D>::NELEM; ++k) rec[k] = 0.0;
-      layer_unit_sw_cold<URBAN, NREG, NS>(L, cu, jlay, rec);
-      SS_UNROLL_FULL
-      for (int e = 0; e < SwRec<N, D>::NELEM; e += 2) w.put2(e, rec[e], rec[e + 1]);
+      using FRec = SwRec<N, D>;          // what the general route writes
+      using LRec = SwLayRec<N, D>;       // what the pipeline reads
+      double rec[FRec::NELEM];
+      for (int k = 0; k < FRec::NELEM; ++k) rec[k] = 0.0;
+      // (device: the cold unit finds the launch descriptor in the kernel-argument segment itself; handing it
+      // &L would make every wave copy the descriptor - 800 bytes per lane - to scratch at kernel entry)
+#if defined(__HIP_DEVICE_COMPILE__)
+      layer_unit_sw_cold<URBAN, NREG, NS>(nullptr, cu, jlay, rec);
+#else
+      layer_unit_sw_cold<URBAN, NREG, NS>(&L, cu, jlay, rec);
+#endif
+      if constexpr (LRec::PACKED) {
+        // R^ = D^-1 R D, T^ likewise: lower triangles (reciprocity makes them symmetric)
+        double rdv[N];
+        for (int i = 0; i < N; ++i) rdv[i] = dsc[i] > 0.0 ? 1.0 / dsc[i] : 0.0;
+        put_packed<N, N, 0>(w, LRec::R, [&](auto ic, auto jc) {
+          constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+          return rec[FRec::R + i + j * N] * (dsc[j] * rdv[i]);
+        });
+        put_packed<N, N, 0>(w, LRec::T, [&](auto ic, auto jc) {
+          constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+          return rec[FRec::T + i + j * N] * (dsc[j] * rdv[i]);
+        });
+        SS_UNROLL_FULL
+        for (int e = 0; e < FRec::NELEM - FRec::SUP; e += 2)
+          w.put2(LRec::SUP + e, rec[FRec::SUP + e], rec[FRec::SUP + e + 1]);
+      } else {
+        SS_UNROLL_FULL
+        for (int e = 0; e < FRec::NELEM; e += 2) w.put2(e, rec[e], rec[e + 1]);
+      }
       return;
     }
   }
@@ -521,14 +546,21 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
 }
 
 template <bool URBAN, int NREG, int NS>
-SS_HD_NOINLINE void layer_unit_sw_cold(const Launch& L, int cu, int jlay, double* rec) {
+SS_HD_NOINLINE void layer_unit_sw_cold(const Launch* Lp, int cu, int jlay, double* rec) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // every kernel that reaches this unit takes the launch descriptor as its only argument, by value
+  (void)Lp;
+  const Launch& L = *(const Launch*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+  const Launch& L = *Lp;
+#endif
   const ArrayRecWriter w{rec, nullptr};
   layer_unit_sw<URBAN, NREG, NS, ArrayRecWriter, 0, true>(L, cu, jlay, w);
 }
 
 template <bool URBAN, int NREG, int NS, int STAGE = 0>
 SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay) {
-  using Rec = SwRec<NREG * NS, NREG>;
+  using Rec = SwLayRec<NREG * NS, NREG>;
   const RecWriter w{L.lay + rec_base(jlay, L.maxlay, Rec::NELEM, cu), kRecStride, (unsigned long long*)L.eigen_fail};
   layer_unit_sw<URBAN, NREG, NS, RecWriter, STAGE>(L, cu, jlay, w);
 }

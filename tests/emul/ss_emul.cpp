@@ -171,41 +171,65 @@ extern "C" int spartacus_radsurf_emul(const ss_config* config, const ss_canopy* 
 }
 
 // ---- unit-level entries of the symmetrised layer route (ss_layer_sym.hpp), TEST-ONLY ----
+// The units write the pipeline's layer record (R^, T^ packed and scaled for the small orders); the entries hand
+// back the layout of LwRec / SwRec (full, un-scaled), which is what the tests compare with the oracle.
 namespace {
-struct ArrayWriter {
-  double* rec;
-  unsigned long long* stamps;
-  void put2(int e, double v0, double v1) const { rec[e] = v0; rec[e + 1] = v1; }
-};
-template <int N, int NSTR>
+template <int N>
+void unpack_rt(const double* in, int offR, int offT, const double* dsc, double* out, int outR, int outT) {
+  for (int j = 0; j < N; ++j)
+    for (int i = 0; i < N; ++i) {
+      const int e = ss::tri_index(N, i >= j ? i : j, i >= j ? j : i);
+      out[outR + i + j * N] = dsc[i] * in[offR + e] / dsc[j];
+      out[outT + i + j * N] = dsc[i] * in[offT + e] / dsc[j];
+    }
+}
+template <int N>
 int lw_sym_unit(const double* g1, const double* g2, const double* b, const double* dsc, double dz, double* rec) {
-  const ArrayWriter w{rec, nullptr};
+  using LR = ss::LwLayRec<N>;
+  using FR = ss::LwRec<N>;
+  double tmp[LR::NELEM + 2] = {0.0};
+  const ss::ArrayRecWriter w{tmp, nullptr};
   const ss::LaneLds<true> lds{};
-  return ss::sym::calc_matrices_lw_sym<N, N, 0>(g1, g2, b, dsc, dz, w, lds);
+  const int rc = ss::sym::calc_matrices_lw_sym<N, N, 0>(g1, g2, b, dsc, dz, w, lds);
+  if (LR::PACKED) unpack_rt<N>(tmp, LR::R, LR::T, dsc, rec, FR::R, FR::T);
+  else for (int k = 0; k < FR::IFLUX; ++k) rec[k] = tmp[k];
+  for (int k = 0; k < FR::NELEM - FR::IFLUX; ++k) rec[FR::IFLUX + k] = tmp[LR::IFLUX + k];
+  return rc;
 }
 template <int N, int D>
 int sw_sym_unit(const double* g0, const double* g1, const double* g2, const double* g3, const double* dsc0,
                 const double* dsc, double dz, double* rec) {
-  const ArrayWriter w{rec, nullptr};
+  using LR = ss::SwLayRec<N, D>;
+  using FR = ss::SwRec<N, D>;
+  double tmp[LR::NELEM + 2] = {0.0};
+  const ss::ArrayRecWriter w{tmp, nullptr};
   const ss::LaneLds<true> lds{};
-  return ss::sym::calc_matrices_sw_sym<N, D, N, D, 0, 0>(g0, g1, g2, g3, dsc0, dsc, dz, w, lds);
+  const int rc = ss::sym::calc_matrices_sw_sym<N, D, N, D, 0, 0>(g0, g1, g2, g3, dsc0, dsc, dz, w, lds);
+  if (LR::PACKED) unpack_rt<N>(tmp, LR::R, LR::T, dsc, rec, FR::R, FR::T);
+  else for (int k = 0; k < FR::SUP; ++k) rec[k] = tmp[k];
+  for (int k = 0; k < FR::NELEM - FR::SUP; ++k) rec[FR::SUP + k] = tmp[LR::SUP + k];
+  return rc;
 }
 }  // namespace
 
 // matrices column-major (n x n); rec receives the LwRec<n> layout (R, T, IFLUX, SRC, ISRC)
 extern "C" int emul_lw_sym_unit(int n, int nstr, const double* g1, const double* g2, const double* b, const double* dsc,
                                 double dz, double* rec) {
+  (void)nstr;
   switch (n) {
-    case 3: return nstr == 1 ? lw_sym_unit<3, 1>(g1, g2, b, dsc, dz, rec) : nstr == 3 ? lw_sym_unit<3, 3>(g1, g2, b, dsc, dz, rec) : -99;
-    case 4: return nstr == 2 ? lw_sym_unit<4, 2>(g1, g2, b, dsc, dz, rec) : nstr == 4 ? lw_sym_unit<4, 4>(g1, g2, b, dsc, dz, rec) : -99;
-    case 6: return nstr == 2 ? lw_sym_unit<6, 2>(g1, g2, b, dsc, dz, rec) : nstr == 3 ? lw_sym_unit<6, 3>(g1, g2, b, dsc, dz, rec) : -99;
+    case 1: return lw_sym_unit<1>(g1, g2, b, dsc, dz, rec);
+    case 2: return lw_sym_unit<2>(g1, g2, b, dsc, dz, rec);
+    case 3: return lw_sym_unit<3>(g1, g2, b, dsc, dz, rec);
+    case 4: return lw_sym_unit<4>(g1, g2, b, dsc, dz, rec);
+    case 5: return lw_sym_unit<5>(g1, g2, b, dsc, dz, rec);
+    case 6: return lw_sym_unit<6>(g1, g2, b, dsc, dz, rec);
     default: return -99;
   }
 }
 extern "C" int emul_lw_rec_offsets(int n, int* off) {
   switch (n) {
 #define OFFS(N) case N: off[0] = ss::LwRec<N>::R; off[1] = ss::LwRec<N>::T; off[2] = ss::LwRec<N>::IFLUX; off[3] = ss::LwRec<N>::SRC; off[4] = ss::LwRec<N>::ISRC; off[5] = ss::LwRec<N>::NELEM; return 0;
-    OFFS(3) OFFS(4) OFFS(6)
+    OFFS(1) OFFS(2) OFFS(3) OFFS(4) OFFS(5) OFFS(6)
 #undef OFFS
     default: return -99;
   }
@@ -217,11 +241,13 @@ extern "C" int emul_sw_sym_unit(int n, int d, const double* g0, const double* g1
   if (n == 4 && d == 2) return sw_sym_unit<4, 2>(g0, g1, g2, g3, dsc0, dsc, dz, rec);
   if (n == 6 && d == 2) return sw_sym_unit<6, 2>(g0, g1, g2, g3, dsc0, dsc, dz, rec);
   if (n == 3 && d == 3) return sw_sym_unit<3, 3>(g0, g1, g2, g3, dsc0, dsc, dz, rec);
+  if (n == 2 && d == 1) return sw_sym_unit<2, 1>(g0, g1, g2, g3, dsc0, dsc, dz, rec);
+  if (n == 2 && d == 2) return sw_sym_unit<2, 2>(g0, g1, g2, g3, dsc0, dsc, dz, rec);
   return -99;
 }
 extern "C" int emul_sw_rec_offsets(int n, int d, int* off) {
 #define OFFS(N, D) if (n == N && d == D) { using R_ = ss::SwRec<N, D>; off[0] = R_::R; off[1] = R_::T; off[2] = R_::SUP; off[3] = R_::SDN; off[4] = R_::EDIR; off[5] = R_::IDIR; off[6] = R_::NELEM; return 0; }
-  OFFS(6, 3) OFFS(4, 2) OFFS(6, 2) OFFS(3, 3)
+  OFFS(6, 3) OFFS(4, 2) OFFS(6, 2) OFFS(3, 3) OFFS(2, 1) OFFS(2, 2)
 #undef OFFS
   return -99;
 }
