@@ -19,7 +19,7 @@ struct LwColRec {
   static constexpr int PDN = 0;                       // P = Den^-1 T      N x N   (Den = I - a_above R)
   static constexpr int ABE = PDN + rec_even(N * N);   // a_below(l+1)      N x N (canopy part)
   // (the small orders store D^-1 a_below D as a packed lower triangle: see SwColRec)
-  static constexpr bool PACKED = sym_packed(N, true);
+  static constexpr bool PACKED = sym_packed_col(N, true);
   static constexpr int NAB = PACKED ? tri_count(N) : N * N;
   static constexpr int SBE = ABE + rec_even(NAB);     // source_below(l+1) N (canopy part)
   static constexpr int RSD = SBE + rec_even(N);       // Den^-1 (R source_above + source_lay)  N

@@ -31,7 +31,7 @@ struct SwColRec {
   static constexpr int ABE = QDN + rec_even(N * D);       // a_below(l+1)      N x N (canopy part)
   // a_below is symmetric in the scaled coordinates of its layer (reciprocity): the small orders store
   // D^-1 a_below D as a packed lower triangle (sym_packed, ss_layer_matrices.hpp)
-  static constexpr bool PACKED = sym_packed(N, false);
+  static constexpr bool PACKED = sym_packed_col(N, false);
   static constexpr int NAB = PACKED ? tri_count(N) : N * N;
   static constexpr int DBE = ABE + rec_even(NAB);         // d_below(l+1)      N x D (canopy part)
   // fused layer + upward kernel (fused_order(N)): no layer record exists, and what the downward
@@ -246,9 +246,10 @@ SS_HD void sw_top_albedos(const Launch& L, long cidx, double cos_sza, const doub
   L.top2[cidx] = s / cos_sza;
 }
 
-// The upward sweep as a kernel of its own (k_column; orders above SS_UNROLL_MAX)
+// The upward sweep in the reference's (unscaled) coordinates: orders whose layer record is not packed
+// (k_column dispatches in ss_column_sw_sym.hpp)
 template <bool URBAN, int NREG, int NS>
-SS_HD void column_up_sw(const Launch& L, int cu) {
+SS_HD void column_up_sw_full(const Launch& L, int cu) {
   constexpr int N = NREG * NS, D = NREG;
   using LRec = SwLayRec<N, D>;
   using CRec = SwColRec<N, D>;
@@ -788,15 +789,6 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
 #undef PUTC
 #undef PUTL
 #undef FSEL
-}
-
-// Whole column on one lane (host emulation and small problems)
-template <bool URBAN, int NREG, int NS>
-SS_HD void column_unit_sw(const Launch& L, int cu) {
-  if constexpr (SwColRec<NREG * NS, NREG>::FUSED) layer_up_sw<URBAN, NREG, NS>(L, cu);
-  else column_up_sw<URBAN, NREG, NS>(L, cu);
-  column_down_sw<URBAN, NREG, NS>(L, cu, 0);
-  column_down_sw<URBAN, NREG, NS>(L, cu, 1);
 }
 
 }  // namespace ss

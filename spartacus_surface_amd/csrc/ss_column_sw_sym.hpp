@@ -1,0 +1,351 @@
+// ss_column_sw_sym.hpp - the shortwave upward sweep (adding method, radsurf_forest_sw.F90:463-528 /
+// radsurf_urban_sw.F90:591-674) in SYMMETRISED coordinates, for the orders whose layer record holds R^ and T^
+// packed (SwLayRec<N, D>::PACKED, ss_layer_matrices.hpp).
+//
+// With u^ = D_l^-1 u, D_l = diag(sqrt(region fraction of layer l) x sqrt(weight mu)) (ss_layer_sym.hpp), the
+// recursion of the reference keeps its form - it is a similarity transform layer by layer - and gains the
+// symmetry the unscaled one hides: R^, T^ and the albedo of everything below an interface, a_above^ / a_below^,
+// are symmetric (reciprocity), so they live as 21 instead of 36 doubles (n = 6), the layer record is read
+// without restoring R = D R^ D^-1, and a_below^ = R^ + T^ X needs its lower triangle only.  The live state of
+// the step drops from ~200 to ~150 doubles: the unscaled form spilled 90 dwords per lane, a quarter of the
+// bytes this bandwidth-bound kernel moved.  The interface to the layer above changes the scaling (its region
+// fractions differ): a_above^ = U^ [a_below^ V^; roof rows] with U^ = D_up^-1 (U x I) D_lo, V^ = D_lo^-1 (V x I) D_up.
+// Direct-beam columns (one per region) stay unscaled; the rows of d_above / d_below / S_up / S_dn are scaled.
+// The column record keeps the layout and the (unscaled) contents the downward sweep reads: P, Q, a_below,
+// d_below are restored on their way out (a multiplication per element, no registers).
+#pragma once
+
+#include "ss_column_sw.hpp"
+#include "ss_layer_sym.hpp"
+
+namespace ss {
+namespace sym {
+
+// sqrt of the region fractions and their reciprocals (0 for a region without area)
+template <int NREG>
+SS_HD void region_roots(const double* frac, double* sf, double* rsf) {
+  SS_UNROLL_FULL
+  for (int r = 0; r < NREG; ++r) {
+    sf[r] = sqrt(frac[r]);
+    rsf[r] = frac[r] > 0.0 ? 1.0 / sf[r] : 0.0;
+  }
+}
+
+// a_above^, d_above^ at the ground (forest :466-477, urban :594-606) in the scaling of the lowest layer
+template <int NREG, int NS>
+SS_HD void sw_ground(const LG& lg, double ga, double gad, double cos_sza, const double* rsf, double* Aab, double* Dab) {
+  constexpr int N = NREG * NS, D = NREG;
+  double swm = 0.0;
+  SS_UNROLL_FULL
+  for (int s = 0; s < NS; ++s) swm += lg.sqrt_wmu[s] * lg.sqrt_wmu[s];
+  const double rs = 1.0 / swm;
+  SS_UNROLL_FULL
+  for (int k = 0; k < kTri<N>; ++k) Aab[k] = 0.0;
+  mat_zero<N, D>(Dab);
+  SS_UNROLL_FULL
+  for (int r = 0; r < NREG; ++r) {
+    SS_UNROLL_FULL
+    for (int sto = 0; sto < NS; ++sto) {
+      // hweight(s) / sqrt_wmu(s) = sqrt_wmu(s) / sum(w mu)
+      SS_E(Dab, sto + r * NS, r, N) = (cos_sza * gad) * (lg.hweight[sto] * lg.rsqrt_wmu[sto]) * rsf[r];
+      SS_UNROLL_FULL
+      for (int sfr = 0; sfr <= sto; ++sfr)
+        Aab[lo<N>(sto + r * NS, sfr + r * NS)] = ga * (lg.sqrt_wmu[sto] * lg.sqrt_wmu[sfr]) * rs;
+    }
+  }
+}
+
+// One layer: consumes R^, T^ (packed), S_up^, S_dn^ (rows scaled), E of the layer record; stores P, Q, a_below,
+// d_below UNSCALED into the column record; returns a_below^ (packed) and d_below^ (rows scaled).
+template <int N, int D>
+SS_HD void sw_adding_step(const double* lrec, const double* Aab, const double* Dab, double* crec,
+                          const double* dsc, const double* rd, double* Abe, double* Dbe) {
+  using LRec = SwLayRec<N, D>;
+  using CRec = SwColRec<N, D>;
+  static_assert(LRec::PACKED && !CRec::PACKED, "packed layer record, full column record");
+  constexpr long st = kRecStride;
+  double R[rec_even(kTri<N>)], T[rec_even(kTri<N>)];
+  rec_load<rec_even(kTri<N>)>(lrec, st, LRec::R, R);
+  rec_load<rec_even(kTri<N>)>(lrec, st, LRec::T, T);
+  SS_LOAD_FENCE(); SS_SCHED_FENCE();
+  // denominator = I - a_above^ R^
+  double Den[N * N];
+  SS_UNROLL_FULL
+  for (int j = 0; j < N; ++j) {
+    SS_UNROLL_FULL
+    for (int i = 0; i < N; ++i) {
+      double s = (i == j) ? 1.0 : 0.0;
+      SS_UNROLL_FULL
+      for (int k = 0; k < N; ++k) s -= Aab[sy<N>(i, k)] * R[sy<N>(k, j)];
+      SS_E(Den, i, j, N) = s;
+    }
+  }
+  lu_factor<N>(Den);
+  double X[N * N];
+  // P^ = Den^-1 T^, stored as P = D P^ D^-1
+  SS_UNROLL_FULL
+  for (int j = 0; j < N; ++j) {
+    SS_UNROLL_FULL
+    for (int i = 0; i < N; ++i) SS_E(X, i, j, N) = T[sy<N>(i, j)];
+  }
+  lu_solve_mat<N, N>(Den, X);
+  SS_UNROLL_FULL
+  for (int j = 0; j < N; ++j) {
+    SS_UNROLL_FULL
+    for (int i = 0; i < N; ++i) SS_E(X, i, j, N) *= dsc[i] * rd[j];
+  }
+  rec_store<N * N>(crec, st, CRec::PDN, X);
+  // a_below^ = R^ + T^ Den^-1 (a_above^ T^): lower triangle
+  SS_UNROLL_FULL
+  for (int j = 0; j < N; ++j) {
+    SS_UNROLL_FULL
+    for (int i = 0; i < N; ++i) {
+      double s = 0.0;
+      SS_UNROLL_FULL
+      for (int k = 0; k < N; ++k) s += Aab[sy<N>(i, k)] * T[sy<N>(k, j)];
+      SS_E(X, i, j, N) = s;
+    }
+  }
+  lu_solve_mat<N, N>(Den, X);
+  SS_UNROLL_FULL
+  for (int j = 0; j < N; ++j) {
+    SS_UNROLL_FULL
+    for (int i = j; i < N; ++i) {
+      double s = R[lo<N>(i, j)];
+      SS_UNROLL_FULL
+      for (int k = 0; k < N; ++k) s += T[sy<N>(i, k)] * SS_E(X, k, j, N);
+      Abe[lo<N>(i, j)] = s;
+    }
+  }
+  // ... stored unscaled and full: a_below = D a_below^ D^-1 (X is free)
+  SS_UNROLL_FULL
+  for (int j = 0; j < N; ++j) {
+    SS_UNROLL_FULL
+    for (int i = 0; i < N; ++i) SS_E(X, i, j, N) = (dsc[i] * rd[j]) * Abe[sy<N>(i, j)];
+  }
+  rec_store<N * N>(crec, st, CRec::ABE, X);
+  // d_below^ = S_up^ + T^ Den^-1 (d_above^ E + a_above^ S_dn^);  Q^ = Den^-1 (R^ (d_above^ E) + S_dn^)
+  double E[D * D], S[N * D], Y[N * D];
+  rec_load<D * D>(lrec, st, LRec::EDIR, E);
+  rec_load<N * D>(lrec, st, LRec::SDN, S);
+  mat_mul<N, D, D>(Dab, E, Y);
+  {
+    double Q[N * D];
+    SS_UNROLL_FULL
+    for (int j = 0; j < D; ++j) {
+      SS_UNROLL_FULL
+      for (int i = 0; i < N; ++i) {
+        double s = SS_E(S, i, j, N);
+        SS_UNROLL_FULL
+        for (int k = 0; k < N; ++k) s += R[sy<N>(i, k)] * SS_E(Y, k, j, N);
+        SS_E(Q, i, j, N) = s;
+      }
+    }
+    lu_solve_mat<N, D>(Den, Q);
+    SS_UNROLL_FULL
+    for (int j = 0; j < D; ++j) {
+      SS_UNROLL_FULL
+      for (int i = 0; i < N; ++i) SS_E(Q, i, j, N) *= dsc[i];
+    }
+    rec_store<N * D>(crec, st, CRec::QDN, Q);
+  }
+  SS_UNROLL_FULL
+  for (int j = 0; j < D; ++j) {
+    SS_UNROLL_FULL
+    for (int i = 0; i < N; ++i) {
+      double s = SS_E(Y, i, j, N);
+      SS_UNROLL_FULL
+      for (int k = 0; k < N; ++k) s += Aab[sy<N>(i, k)] * SS_E(S, k, j, N);
+      SS_E(Y, i, j, N) = s;
+    }
+  }
+  lu_solve_mat<N, D>(Den, Y);
+  rec_load<N * D>(lrec, st, LRec::SUP, S);
+  SS_UNROLL_FULL
+  for (int j = 0; j < D; ++j) {
+    SS_UNROLL_FULL
+    for (int i = 0; i < N; ++i) {
+      double s = SS_E(S, i, j, N);
+      SS_UNROLL_FULL
+      for (int k = 0; k < N; ++k) s += T[sy<N>(i, k)] * SS_E(Y, k, j, N);
+      SS_E(Dbe, i, j, N) = s;
+    }
+  }
+  SS_UNROLL_FULL
+  for (int j = 0; j < D; ++j) {
+    SS_UNROLL_FULL
+    for (int i = 0; i < N; ++i) SS_E(S, i, j, N) = dsc[i] * SS_E(Dbe, i, j, N);
+  }
+  rec_store<N * D>(crec, st, CRec::DBE, S);
+}
+
+// Overlap to the base of the layer above layer jlay, or to the free atmosphere (forest :495-503, urban
+// :627-653), from the scaling of layer jlay (sf_lo, rsf_lo) into that of the layer above (returned in
+// sf_up, rsf_up): a_above^ = U^ [a_below^ V^; roof rows], d_above^ likewise.
+template <bool URBAN, int NREG, int NS>
+SS_HD void sw_overlap_above(const Launch& L, int cu, int jlay, int nlay, double cos_sza, const double* Abe,
+                            const double* Dbe, const double* sf_lo, const double* rsf_lo, double* sf_up,
+                            double* rsf_up, double* Aab, double* Dab) {
+  constexpr int N = NREG * NS, D = NREG;
+  constexpr int DB = URBAN ? NREG + 1 : NREG;
+  const LG& lg = L.lg;
+  double U[NREG * DB], V[DB * NREG];
+  const double* prec = pack_rec(L, jlay, cu, kPackSw);
+  double vf_lo, bf_lo, vf_up = 0.0, bf_up = 0.0;
+  pack_fractions(prec, vf_lo, bf_lo);
+  const bool sky = jlay + 1 >= nlay;
+  if (!sky) pack_fractions(pack_rec(L, jlay + 1, cu, kPackSw), vf_up, bf_up);
+  interface_overlap_vals<URBAN, false, NREG>(L.cfg.min_vegetation_fraction, sky, vf_up, bf_up, false, vf_lo, bf_lo, U, V);
+  {
+    double fu[NREG];
+    if (sky) {
+      fu[0] = 1.0;
+      SS_UNROLL_FULL
+      for (int r = 1; r < NREG; ++r) fu[r] = 0.0;
+    } else {
+      region_fractions<URBAN, false, NREG>((NREG > 1) ? vf_up : 0.0, URBAN ? bf_up : 0.0, fu);
+    }
+    region_roots<NREG>(fu, sf_up, rsf_up);
+  }
+  double roof_a = 0.0, roof_d = 0.0;
+  if (URBAN) {
+    const RecPair ra = rec_pair_load(prec + 8 * kRecStride);   // roof_albedo, roof_albedo_dir
+    roof_a = ra.x;
+    roof_d = cos_sza * ra.y;
+  }
+  // Vs = V^ (diffuse columns: scaled on both sides), Us = U^
+  double Vs[DB * NREG], Us[NREG * DB];
+  SS_UNROLL_FULL
+  for (int ju = 0; ju < NREG; ++ju) {
+    SS_UNROLL_FULL
+    for (int jl = 0; jl < DB; ++jl) {
+      const double lo_s = (jl < NREG) ? sf_lo[jl < NREG ? jl : 0] : 1.0, lo_r = (jl < NREG) ? rsf_lo[jl < NREG ? jl : 0] : 1.0;
+      SS_E(Vs, jl, ju, DB) = SS_E(V, jl, ju, DB) * (sf_up[ju] * lo_r);
+      SS_E(Us, ju, jl, NREG) = SS_E(U, ju, jl, NREG) * (lo_s * rsf_up[ju]);
+    }
+  }
+  // tA = a_below^ (V^ (x) I): canopy rows (N x N) and roof rows (NS x N; roof components scaled by sqrt(weight mu))
+  double tA[N * N], tAroof[NS * N];
+  SS_UNROLL_FULL
+  for (int ju = 0; ju < NREG; ++ju) {
+    SS_UNROLL_FULL
+    for (int s = 0; s < NS; ++s) {
+      const int cc = ju * NS + s;
+      SS_UNROLL_FULL
+      for (int i = 0; i < N; ++i) {
+        double acc = 0.0;
+        SS_UNROLL_FULL
+        for (int jl = 0; jl < NREG; ++jl) acc += Abe[sy<N>(i, jl * NS + s)] * SS_E(Vs, jl, ju, DB);
+        SS_E(tA, i, cc, N) = acc;
+      }
+      SS_UNROLL_FULL
+      for (int sr = 0; sr < NS; ++sr)
+        SS_E(tAroof, sr, cc, NS) = URBAN ? (roof_a * lg.hweight[sr] * lg.rsqrt_wmu[sr]) * (SS_E(Vs, DB - 1, ju, DB) * lg.sqrt_wmu[s]) : 0.0;
+    }
+  }
+  {
+    double Af[N * N];
+    apply_U_mat<NREG, DB, NS, N>(Us, tA, tAroof, Af);
+    SS_UNROLL_FULL
+    for (int j = 0; j < N; ++j) {
+      SS_UNROLL_FULL
+      for (int i = j; i < N; ++i) Aab[lo<N>(i, j)] = 0.5 * (SS_E(Af, i, j, N) + SS_E(Af, j, i, N));
+    }
+  }
+  // tD = d_below^ V (direct-beam columns unscaled): canopy rows and roof rows
+  double tD[N * D], tDroof[NS * D];
+  SS_UNROLL_FULL
+  for (int ju = 0; ju < NREG; ++ju) {
+    SS_UNROLL_FULL
+    for (int i = 0; i < N; ++i) {
+      double acc = 0.0;
+      SS_UNROLL_FULL
+      for (int jl = 0; jl < NREG; ++jl) acc += SS_E(Dbe, i, jl, N) * SS_E(V, jl, ju, DB);
+      SS_E(tD, i, ju, N) = acc;
+    }
+    SS_UNROLL_FULL
+    for (int sr = 0; sr < NS; ++sr)
+      SS_E(tDroof, sr, ju, NS) = URBAN ? (roof_d * lg.hweight[sr] * lg.rsqrt_wmu[sr]) * SS_E(V, DB - 1, ju, DB) : 0.0;
+  }
+  apply_U_mat<NREG, DB, NS, D>(Us, tD, tDroof, Dab);
+}
+
+// top-of-canopy albedos (forest :520-528, urban :666-674): the clear-sky region of the free atmosphere
+// (fraction 1: its scaling is sqrt(weight mu))
+template <int NREG, int NS>
+SS_HD void sw_top_albedos(const Launch& L, long cidx, double cos_sza, const double* Aab, const double* Dab) {
+  constexpr int N = NREG * NS;
+  const LG& lg = L.lg;
+  double s = 0.0;
+  SS_UNROLL_FULL
+  for (int j1 = 0; j1 < NS; ++j1) {
+    double acc = 0.0;
+    SS_UNROLL_FULL
+    for (int j2 = 0; j2 < NS; ++j2) acc += Aab[sy<N>(j1, j2)] * (lg.rsqrt_wmu[j2] * lg.hweight[j2]);
+    s += lg.sqrt_wmu[j1] * acc;
+  }
+  L.top1[cidx] = s;
+  s = 0.0;
+  SS_UNROLL_FULL
+  for (int j1 = 0; j1 < NS; ++j1) s += lg.sqrt_wmu[j1] * SS_E(Dab, j1, 0, N);
+  L.top2[cidx] = s / cos_sza;
+}
+
+// The upward sweep of one column unit (k_column)
+template <bool URBAN, int NREG, int NS>
+SS_HD void column_up_sw(const Launch& L, int cu) {
+  constexpr int N = NREG * NS, D = NREG;
+  using LRec = SwLayRec<N, D>;
+  using CRec = SwColRec<N, D>;
+  const Inputs& in = L.in;
+  const SwColCtx<URBAN, NREG, NS> c(L, cu, false);
+  double Aab[kTri<N>], Dab[N * D];
+  double sf[NREG], rsf[NREG];
+  {
+    double vf = 0.0, bf = 0.0, frac[NREG];
+    if (c.nlay > 0) pack_fractions(pack_rec(L, 0, cu, kPackSw), vf, bf);
+    region_fractions<URBAN, false, NREG>(vf, bf, frac);
+    region_roots<NREG>(frac, sf, rsf);
+  }
+  sym::sw_ground<NREG, NS>(L.lg, in.ground_albedo[c.cidx], in.ground_albedo_dir[c.cidx], c.cos_sza, rsf, Aab, Dab);
+  for (int jlay = 0; jlay < c.nlay; ++jlay) {
+    const double* lrec = L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu);
+    double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
+    double dsc[N], rd[N];
+    SS_UNROLL_FULL
+    for (int r = 0; r < NREG; ++r) {
+      SS_UNROLL_FULL
+      for (int s = 0; s < NS; ++s) {
+        dsc[s + r * NS] = sf[r] * L.lg.sqrt_wmu[s];
+        rd[s + r * NS] = rsf[r] * L.lg.rsqrt_wmu[s];
+      }
+    }
+    double Abe[kTri<N>], Dbe[N * D];
+    sym::sw_adding_step<N, D>(lrec, Aab, Dab, crec, dsc, rd, Abe, Dbe);
+    double sfu[NREG], rsfu[NREG];
+    sym::sw_overlap_above<URBAN, NREG, NS>(L, cu, jlay, c.nlay, c.cos_sza, Abe, Dbe, sf, rsf, sfu, rsfu, Aab, Dab);
+    SS_UNROLL_FULL
+    for (int r = 0; r < NREG; ++r) { sf[r] = sfu[r]; rsf[r] = rsfu[r]; }
+  }
+  sym::sw_top_albedos<NREG, NS>(L, c.cidx, c.cos_sza, Aab, Dab);
+}
+
+}  // namespace sym
+
+// The upward sweep of one column unit (k_column): in symmetrised coordinates where the layer record is packed
+template <bool URBAN, int NREG, int NS>
+SS_HD void column_up_sw(const Launch& L, int cu) {
+  if constexpr (SwLayRec<NREG * NS, NREG>::PACKED) sym::column_up_sw<URBAN, NREG, NS>(L, cu);
+  else column_up_sw_full<URBAN, NREG, NS>(L, cu);
+}
+
+// Whole column on one lane (host emulation and small problems)
+template <bool URBAN, int NREG, int NS>
+SS_HD void column_unit_sw(const Launch& L, int cu) {
+  if constexpr (SwColRec<NREG * NS, NREG>::FUSED) layer_up_sw<URBAN, NREG, NS>(L, cu);
+  else column_up_sw<URBAN, NREG, NS>(L, cu);
+  column_down_sw<URBAN, NREG, NS>(L, cu, 0);
+  column_down_sw<URBAN, NREG, NS>(L, cu, 1);
+}
+
+}  // namespace ss

@@ -4,6 +4,7 @@
 #include "ss_kernels.hpp"
 #include "ss_column_lw.hpp"
 #include "ss_column_sw.hpp"
+#include "ss_column_sw_sym.hpp"
 #include "ss_solver_lw.hpp"
 #include "ss_solver_sw.hpp"
 #include "ss_layer16.hpp"
@@ -143,8 +144,14 @@ __global__ void __launch_bounds__(kBlock16, 2) k_column16(const Launch L) {
 }
 
 // upward sweep (adding method)
+#ifndef SS_COLUMN_WAVES_ATTR
+#define SS_COLUMN_WAVES_ATTR
+#endif
+#ifndef SS_DOWN_WAVES_ATTR
+#define SS_DOWN_WAVES_ATTR
+#endif
 template <bool U, int R, int NS, bool LW>
-__global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_COLUMN)) k_column(const Launch L) {
+__global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_COLUMN)) SS_COLUMN_WAVES_ATTR k_column(const Launch L) {
   const int cu = blockIdx.x * kBlock + threadIdx.x;
   if (cu >= L.ncu) return;
   if (LW) column_up_lw<U, R, NS>(L, cu);
@@ -164,7 +171,7 @@ __global__ void __launch_bounds__(kBlock16, 2) k_down16(const Launch L) {
 
 // downward flux sweep: vectors only, several waves per SIMD
 template <bool U, int R, int NS, bool LW>
-__global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_DOWN)) k_down(const Launch L) {
+__global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_DOWN)) SS_DOWN_WAVES_ATTR k_down(const Launch L) {
   const int unit = blockIdx.x * kBlock + threadIdx.x;   // (column unit, pass), pass fastest
   const int cu = unit >> 1;
   if (cu >= L.ncu) return;

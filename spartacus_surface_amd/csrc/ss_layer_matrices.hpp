@@ -75,20 +75,23 @@ struct LwRec {
 // record 128 -> 98 doubles, the longwave one 120 -> 90); the upward sweep restores R = D R^ D^-1 with the
 // scaling of its layer.  Every other order keeps the layout of SwRec / LwRec, which also remains the
 // layout of the general route (ss_layer_matrices.hpp, the kernel-level entries, the cold path).
-// Measured (C3, one stream, ms per step; tools/run_variants.sh): packing pays for the longwave (layer 3.29 ->
-// 3.12, upward sweep 3.11 -> 2.83, downward 2.58 -> 2.42) and costs in the shortwave, whose upward sweep is
-// short of registers (restoring R and T from 2 x 21 into 2 x 36 doubles next to a_above, d_above, S_up, S_dn:
-// 88 -> 121 spilled dwords, 3.81 -> 5.56 ms; the downward sweep 4.13 -> 4.41): the shortwave keeps full
-// records (-DSS_SYM_PACK_SW packs it too).
+// Layer record (R^, T^): packed for both spectral regions.  The shortwave upward sweep then runs in the
+// scaled coordinates (ss_column_sw_sym.hpp); restoring R = D R^ D^-1 into full matrices next to a_above,
+// d_above, S_up, S_dn was measured and costs more than the bytes save (88 -> 121 spilled dwords, upward sweep
+// 3.81 -> 5.56 ms per step).  -DSS_NO_SYM_PACK_SW: full shortwave records, unscaled sweep.
 constexpr bool sym_packed(int nf, bool lw) {
 #if defined(SS_NO_SYM_LAYER) || defined(SS_FUSE_SW) || defined(SS_FUSE_LW)
   return false && nf > 0 && lw;
-#elif defined(SS_SYM_PACK_SW)
-  return nf >= 3 && nf <= SS_UNROLL_MAX && (lw || true);
-#else
+#elif defined(SS_NO_SYM_PACK_SW)
   return lw && nf >= 3 && nf <= SS_UNROLL_MAX;
+#else
+  return nf >= 3 && nf <= SS_UNROLL_MAX && (lw || true);
 #endif
 }
+// Column record (a_below): packed and scaled for the longwave (layer 3.29 -> 3.12, upward sweep 3.11 -> 2.83,
+// downward 2.58 -> 2.42 ms per step with both packings); the shortwave downward sweep reads it unscaled (with
+// the packed form it went 4.13 -> 4.41).
+constexpr bool sym_packed_col(int nf, bool lw) { return lw && sym_packed(nf, lw); }
 constexpr int tri_count(int n) { return n * (n + 1) / 2; }
 // packed lower triangle, column by column: index of (i, j), i >= j, and back
 constexpr int tri_index(int n, int i, int j) { return i + j * n - j * (j + 1) / 2; }

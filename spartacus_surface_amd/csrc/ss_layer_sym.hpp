@@ -605,8 +605,10 @@ SS_HD int calc_matrices_sw_sym(const double* g0, const double* g1, const double*
     symv<N>(Wm, xm, wm);
     SS_UNROLL_FULL
     for (int i = 0; i < N; ++i) {
-      SS_E(su, i, jd, N) = dsc[i] * (p[i] - wp[i] - wm[i]);
-      SS_E(sd, i, jd, N) = dsc[i] * (e * p[i] - wp[i] + wm[i]);
+      // (rows scaled where the record is packed: the upward sweep then works in the scaled coordinates)
+      const double un = Rec::PACKED ? 1.0 : dsc[i];
+      SS_E(su, i, jd, N) = un * (p[i] - wp[i] - wm[i]);
+      SS_E(sd, i, jd, N) = un * (e * p[i] - wp[i] + wm[i]);
     }
   }
   {

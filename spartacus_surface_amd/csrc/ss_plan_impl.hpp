@@ -40,6 +40,7 @@
 #include "ss_misc_units.hpp"
 #include "ss_column_lw.hpp"
 #include "ss_column_sw.hpp"
+#include "ss_column_sw_sym.hpp"
 #include "ss_solver_lw.hpp"
 #include "ss_solver_sw.hpp"
 
@@ -87,7 +88,7 @@ inline int col_nelem(bool lw, const ClassKey& k) {
   // = LwColRec<n>::NELEM / SwColRec<n,d>::NELEM (ss_column_lw.hpp, ss_column_sw.hpp)
   auto ev = [](int x) { return (x + 1) & ~1; };
   // a_below is packed (scaled, symmetric) for the small orders
-  const int ab = sym_packed(n, lw) ? tri_count(n) : n * n;
+  const int ab = sym_packed_col(n, lw) ? tri_count(n) : n * n;
   const int base = lw ? ev(n * n) + ev(ab) + 2 * ev(n) : ev(n * n) + ev(ab) + 2 * ev(n * d);
   if (!fused_order(n, lw)) return base;
 #if defined(SS_FUSE_VIA_RECORD)

@@ -528,6 +528,9 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
           constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
           return rec[FRec::T + i + j * N] * (dsc[j] * rdv[i]);
         });
+        // S_up, S_dn: rows scaled; E, int_dir as they are
+        for (int j = 0; j < D; ++j)
+          for (int i = 0; i < N; ++i) { rec[FRec::SUP + i + j * N] *= rdv[i]; rec[FRec::SDN + i + j * N] *= rdv[i]; }
         SS_UNROLL_FULL
         for (int e = 0; e < FRec::NELEM - FRec::SUP; e += 2)
           w.put2(LRec::SUP + e, rec[FRec::SUP + e], rec[FRec::SUP + e + 1]);

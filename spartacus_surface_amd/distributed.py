@@ -4,9 +4,10 @@ Columns are independent (radsurf_interface.F90:105), so the path shards with no
 data-path collective: every rank owns a contiguous range of columns together
 with the matching packed layer range (istartlay / nlay,
 radsurf_canopy_properties.F90:56-59), solves it with its own plan on its own
-GPU, and the only exchange is the final gather of the results.  RCCL (like
-NCCL) has no gatherv, so shards are padded to the largest shard and exchanged
-with one all_gather per array; rank 0 strips the padding.
+GPU, and the only exchange is the final gather of the results: point-to-point
+sends of every output array into its slice of rank 0's full-size array
+(DeviceGather); gather_flat_outputs is the simple padded all_gather form the
+CPU tests compare it with.
 
 The functions take the process group's tensors as they come: CPU tensors with
 the ``gloo`` backend (unit tests), device tensors with ``nccl`` (= RCCL).
@@ -164,12 +165,16 @@ def _per_column(name):
 
 class DeviceGather:
     """Gather of bc_out and the four flux objects of every rank's plan to rank
-    ``root``, from device memory to device memory: every rank packs its output
-    arrays (views of ``ss_plan_device_ptr``, no host staging) into one send buffer
-    padded to the largest shard, ONE ``gather`` (grouped send/recv in RCCL: each
-    peer pushes its shard over its own xGMI link into the root) moves it, and the
-    root strips the padding into full-size device arrays.  There is no reduction
-    and no all-to-all: the ring bound of an all-reduce does not apply.
+    ``root``, from device memory to device memory, WITHOUT intermediate buffers:
+    per-column and per-layer ranges of a rank are contiguous in the full arrays
+    (radsurf_canopy_properties.F90:56-59), so every peer sends each of its output
+    arrays as it lies in its plan (views of ``ss_plan_device_ptr``) and the root
+    receives it straight into the slice of the full-size array it belongs to - one
+    batch of point-to-point operations (``batch_isend_irecv``: grouped send/recv in
+    RCCL, each peer pushes over its own xGMI link into the root).  No padding to the
+    largest shard, no packing pass on the senders, no unpacking pass on the root: the
+    root holds the outputs once.  There is no reduction and no all-to-all: the ring
+    bound of an all-reduce does not apply.
 
     names=None gathers everything; a subset (e.g. the four bc_out arrays that a
     host atmosphere model needs every step) gets its own instance.
@@ -184,27 +189,16 @@ class DeviceGather:
         self.dist = dist
         self.plan = plan
         self.root = root
-        self.stage_host = stage_host
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
         self.names = list(names) if names is not None else output_names(plan)
-        on_host = hasattr(plan, "host_array")            # HostArrays stand-in (CPU tests)
-        stage_host = self.stage_host = stage_host or on_host
-        dev = torch.device("cpu") if on_host else torch.device("cuda", plan.device())
-        self.device = dev
-        cdev = torch.device("cpu") if stage_host else dev
-        self.views, widths = [], []
-        for n in self.names:
-            ptr, nelem = plan.device_ptr(n)
-            rows = ncol_local if _per_column(n) else ntotlay_local
-            # logical size: rows x width (an array of an empty shard still has one element allocated)
-            width = (nelem // rows) if rows > 0 else 0
-            widths.append(width)
-            used = rows * width
-            if on_host:
-                self.views.append(torch.from_numpy(plan.host_array(n).reshape(-1))[:used])
-            else:
-                self.views.append(torch.as_tensor(_DevArray(ptr, max(1, nelem)), device=dev)[:used])
+        self.on_host = hasattr(plan, "host_array")            # HostArrays stand-in (CPU tests)
+        self.stage_host = stage_host or self.on_host
+        self.device = torch.device("cpu") if self.on_host else torch.device("cuda", plan.device())
+        cdev = torch.device("cpu") if self.stage_host else self.device
+        self.rows_local = (ncol_local, ntotlay_local)
+        self._ptrs = None
+        widths = self._make_views()
         # every rank learns every rank's (ncol, ntotlay) and the member widths (identical on ranks with data)
         meta = torch.tensor([ncol_local, ntotlay_local] + widths, dtype=torch.int64, device=cdev)
         allmeta = [torch.zeros_like(meta) for _ in range(self.world)]
@@ -213,50 +207,73 @@ class DeviceGather:
         self.ncols = [int(m[0]) for m in allmeta]
         self.nlays = [int(m[1]) for m in allmeta]
         self.widths = [int(max(m[2 + i] for m in allmeta)) for i in range(len(self.names))]
-        # layout of the packed buffer: per member a slot of (largest shard rows) x width
-        maxc, maxl = max(self.ncols), max(self.nlays)
-        self.slot = [(maxc if _per_column(n) else maxl) * w for n, w in zip(self.names, self.widths)]
-        self.offset = np.concatenate(([0], np.cumsum(self.slot))).astype(np.int64)
-        total = int(self.offset[-1])
-        self.send = torch.zeros(max(1, total), dtype=torch.float64, device=cdev)
-        self.recv = None
         self.full = None
         if self.rank == root:
-            self.recv = [torch.empty_like(self.send) for _ in range(self.world)]
             self.full = {}
             tc, tl = sum(self.ncols), sum(self.nlays)
             for n, w in zip(self.names, self.widths):
                 rows = tc if _per_column(n) else tl
                 self.full[n] = torch.zeros(rows * w, dtype=torch.float64, device=cdev)
-        self.bytes_per_rank = 8 * total
+        self.bytes_per_rank = 8 * sum((ncol_local if _per_column(n) else ntotlay_local) * w
+                                      for n, w in zip(self.names, self.widths))
+
+    def _make_views(self):
+        """Views of the plan's output arrays.  A plan may re-allocate them (its arrays grow when it is
+        re-targeted): the addresses are re-queried at every call and the views rebuilt when they moved."""
+        torch = self.torch
+        ptrs = [self.plan.device_ptr(n) for n in self.names]
+        if ptrs == self._ptrs:
+            return None
+        self._ptrs = ptrs
+        self.views, widths = [], []
+        for n, (ptr, nelem) in zip(self.names, ptrs):
+            rows = self.rows_local[0] if _per_column(n) else self.rows_local[1]
+            # logical size: rows x width (an array of an empty shard still has one element allocated)
+            width = (nelem // rows) if rows > 0 else 0
+            widths.append(width)
+            used = rows * width
+            if self.on_host:
+                self.views.append(torch.from_numpy(self.plan.host_array(n).reshape(-1))[:used])
+            else:
+                self.views.append(torch.as_tensor(_DevArray(ptr, max(1, nelem)), device=self.device)[:used])
+        return widths
 
     def __call__(self):
-        """Pack, gather, unpack.  The plan's streams must be idle (plan.synchronize())."""
+        """One batch of sends (peers) / receives into place (root).  The plan's streams must be idle
+        (plan.synchronize())."""
         torch, dist = self.torch, self.dist
-        for i, v in enumerate(self.views):
-            if v.numel():
-                o = int(self.offset[i])
-                self.send[o:o + v.numel()].copy_(v)
+        self._make_views()
         if not self.stage_host:
             torch.cuda.synchronize(self.device)
-        dist.gather(self.send, self.recv if self.rank == self.root else None, dst=self.root)
-        if self.rank != self.root:
-            return None
-        c0 = l0 = 0
-        for r in range(self.world):
-            for i, n in enumerate(self.names):
-                rows = self.ncols[r] if _per_column(n) else self.nlays[r]
-                cnt = rows * self.widths[i]
-                if cnt == 0:
-                    continue
-                start = (c0 if _per_column(n) else l0) * self.widths[i]
-                o = int(self.offset[i])
-                self.full[n][start:start + cnt].copy_(self.recv[r][o:o + cnt])
-            c0 += self.ncols[r]
-            l0 += self.nlays[r]
+        ops, keep = [], []
+        if self.rank == self.root:
+            c0 = l0 = 0
+            for r in range(self.world):
+                for i, n in enumerate(self.names):
+                    rows = self.ncols[r] if _per_column(n) else self.nlays[r]
+                    cnt = rows * self.widths[i]
+                    if cnt == 0:
+                        continue
+                    start = (c0 if _per_column(n) else l0) * self.widths[i]
+                    dst = self.full[n][start:start + cnt]
+                    if r == self.rank:
+                        dst.copy_(self.views[i])
+                    else:
+                        ops.append(dist.P2POp(dist.irecv, dst, r))
+                c0 += self.ncols[r]
+                l0 += self.nlays[r]
+        else:
+            for v in self.views:
+                if v.numel():
+                    t = v.cpu() if (self.stage_host and not self.on_host) else v
+                    keep.append(t)
+                    ops.append(dist.P2POp(dist.isend, t, self.root))
+        if ops:
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
         if not self.stage_host:
             torch.cuda.synchronize(self.device)
-        return self.full
+        return self.full if self.rank == self.root else None
 
     def to_host(self):
         """{name: ndarray (rows, width)} of the assembled arrays (root only)."""

@@ -108,8 +108,9 @@ def rami5_replicated(ncol=20_000, scene="HET09_JBS_SUM-41-direct"):
     no longwave) replicated `ncol` times."""
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden",
-                        "rami5__%s.npz" % scene)
+    # inputs of that one column (data of the reference's test/rami5 scene files, extracted by
+    # tools/extract_rami5_column.py): the package does not read the test fixtures
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "rami5__%s_inputs.npz" % scene)
     z = np.load(path)
     meta = json.loads(bytes(z["meta"]).decode())
     meta.pop("do_simple_spectrum")
@@ -309,10 +310,12 @@ def ragged_all_tiles(ncol=96, seed=2024, nsw=2, nlw=3, simple_urban=True):
 
 # Algorithmic HBM bytes per column: fp64 inputs the solver
 # reads + outputs it writes, no flux profiles.
-def algorithmic_bytes_per_column(case):
+def algorithmic_bytes_per_column(case, family=None):
+    """(bytes in, bytes out) per column of SURVEY.md section 8(d); family "sw" / "lw": what one spectral
+    region alone reads and writes (the band-independent geometry counted with each)."""
     cfg, cp = case["config"], case["canopy"]
-    S = cfg.nsw if cfg.do_sw else 0
-    W = cfg.nlw if cfg.do_lw else 0
+    S = cfg.nsw if (cfg.do_sw and family != "lw") else 0
+    W = cfg.nlw if (cfg.do_lw and family != "sw") else 0
     L = float(cp.ntotlay) / max(1, cp.ncol)
     urban = float(np.mean(cp.i_representation != ITileForest))
     # per layer: geometry doubles g, SW spectral s, LW spectral w

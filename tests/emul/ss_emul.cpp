@@ -208,6 +208,9 @@ int sw_sym_unit(const double* g0, const double* g1, const double* g2, const doub
   if (LR::PACKED) unpack_rt<N>(tmp, LR::R, LR::T, dsc, rec, FR::R, FR::T);
   else for (int k = 0; k < FR::SUP; ++k) rec[k] = tmp[k];
   for (int k = 0; k < FR::NELEM - FR::SUP; ++k) rec[FR::SUP + k] = tmp[LR::SUP + k];
+  if (LR::PACKED)
+    for (int j = 0; j < D; ++j)
+      for (int i = 0; i < N; ++i) { rec[FR::SUP + i + j * N] *= dsc[i]; rec[FR::SDN + i + j * N] *= dsc[i]; }
   return rc;
 }
 }  // namespace

@@ -30,7 +30,7 @@ REFERENCE_SINGULAR = {"simple__test_noscat": (1.0e-3, 5.0e-2)}
 # Every comparison of this module leaves its full report here: per case and variable
 # {measured error, bar, the reference's own noise, both distances from binary128}.
 # Written to gpurun_out/parity_report.json at the end of the session; the copy of the
-# round's final GPU run is committed as profiles/parity_r2.json.
+# round's final GPU run is committed as profiles/parity_r3.json.
 _REPORT = {}
 
 
@@ -263,6 +263,22 @@ def test_synthetic_c4_mixed_multiband_vs_oracle():
     from spartacus_surface_amd import workloads
     case = workloads.c4_mixed(ncol=512, seed=12345)
     _, bad = _check_against_oracle(case, 512, "synthetic/c4_512")
+    assert not bad, bad[:5]
+
+
+def test_synthetic_c3_four_streams_vs_oracle():
+    """C3 with 4 streams (n = 12: the kernels of the orders 7..16 on DPP rows), jittered many-column sample."""
+    from spartacus_surface_amd import workloads
+    case = workloads.c3_vegetated_urban(ncol=2048, seed=12345, nstream=4)
+    _, bad = _check_against_oracle(case, 2048, "synthetic/c3ns4_2048")
+    assert not bad, bad[:5]
+
+
+def test_synthetic_c4_four_streams_multiband_vs_oracle():
+    """C4 with 4 streams: mixed forest / vegetated-urban columns, 14 SW + 16 LW bands, n = 12 in both tile kinds."""
+    from spartacus_surface_amd import workloads
+    case = workloads.c4_mixed(ncol=256, seed=12345, nstream=4)
+    _, bad = _check_against_oracle(case, 256, "synthetic/c4ns4_256")
     assert not bad, bad[:5]
 
 

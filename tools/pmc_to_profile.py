@@ -102,8 +102,13 @@ if "layer_both" in traffic:
             t[k] += 0.5 * both[k]
 json.dump(out, open("profiles/%s_pmc.json" % tag, "w"), indent=1)
 json.dump({"source": "profiles/%s_pmc.json" % tag, "workload": "%s, %d columns" % (workload, ncol),
-           "note": "HBM bytes per column per kernel family from FETCH_SIZE (x2, gfx950 correction of "
-                   "MI355X_MICROARCH.md) + WRITE_SIZE; separate --pmc passes",
+           "note": "bytes per column per kernel family between the L2s and the fabric: FETCH_SIZE x 2 + WRITE_SIZE, "
+                   "separate --pmc passes.  The x 2 is the gfx950 correction of MI355X_MICROARCH.md for 16-byte-per-lane "
+                   "streaming reads, which is what these kernels issue for their records, input packs and spill "
+                   "reloads (global_load_dwordx4 / scratch_load_dwordx4); the few narrower reads (8-byte inputs "
+                   "of the pack kernel, 4-byte index loads) are uncalibrated there, so the read part is an upper "
+                   "bound.  WRITE_SIZE is exact for the 16-byte record stores; the 8-byte per-layer output stores "
+                   "of the downward kernels are uncalibrated.  Infinity-Cache hits are included: HBM itself may see less.",
            "bytes_per_column": {f: t["fetch_x2"] + t["write"] for f, t in traffic.items()},
            "fp64_flops_per_column_executed": {f: t["flops"] for f, t in traffic.items()}},
           open(traffic_file, "w"), indent=1)
