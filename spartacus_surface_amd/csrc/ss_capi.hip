@@ -363,6 +363,15 @@ struct HipBackend {
     }
     copy_async(h, d, n, hipMemcpyDeviceToHost, stream());
   }
+  // The stream downloads of this plan's results go to, ordered behind everything queued on the main stream so far
+  hipStream_t gate_downloads() {
+    if (!down_) return stream();
+    if (!gate_ev_) HIP_CHECK_THROW(hipEventCreateWithFlags(&gate_ev_, hipEventDisableTiming));
+    HIP_CHECK_THROW(hipEventRecord(gate_ev_, stream()));
+    HIP_CHECK_THROW(hipStreamWaitEvent(down_, gate_ev_, 0));
+    main_dirty_ = false;
+    return down_;
+  }
   void gate_copies() {}      // copies queued now already run after everything queued before them
   // (One copy KERNEL per chunk that stores straight into mapped host memory, instead of ~35
   // DMA copies with ~30 us between them, was measured slower - 1.18e7 -> 0.90e7 columns/s: its
@@ -742,6 +751,8 @@ struct ColumnOutput {
   double* host;
   int width;
 };
+// the per-layer output members of a call (same record: width = doubles per layer)
+std::vector<ColumnOutput> layer_outputs(const ss_config* cfg, int profiles, ss_flux* const* fl);
 // Only the members a plan of this configuration allocates and writes (flux_member_present): a caller
 // may pass more (an LW flux object with its *_dir members allocated, roof members without do_urban);
 // those stay untouched, exactly as the per-chunk download skips device arrays the plan does not have.
@@ -764,6 +775,22 @@ std::vector<ColumnOutput> column_outputs(const ss_config* cfg, int profiles, ss_
       if ((shape == 0 || shape == 2) && m[F] && ss::flux_member_present_for(*cfg, profiles != 0, F, k < 2))
         out.push_back({std::string(obj[k]) + "." + HipPlan::flux_field_name(F), m[F],
                        shape == 0 ? (k < 2 ? cfg->nsw : cfg->nlw) : 1});
+    }
+  }
+  return out;
+}
+
+std::vector<ColumnOutput> layer_outputs(const ss_config* cfg, int profiles, ss_flux* const* fl) {
+  static const char* obj[4] = {"sw_norm_dir", "sw_norm_diff", "lw_internal", "lw_norm"};
+  std::vector<ColumnOutput> out;
+  for (int k = 0; k < 4; ++k) {
+    if (!fl[k]) continue;
+    double* const* m = &fl[k]->ground_dn;
+    for (int F = 0; F < ss::F_NFIELDS; ++F) {
+      const int shape = ss::flux_field_shape(F);
+      if ((shape == 1 || shape == 3) && m[F] && ss::flux_member_present_for(*cfg, profiles != 0, F, k < 2))
+        out.push_back({std::string(obj[k]) + "." + HipPlan::flux_field_name(F), m[F],
+                       shape == 1 ? (k < 2 ? cfg->nsw : cfg->nlw) : 1});
     }
   }
   return out;
@@ -1056,10 +1083,15 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
     // SPARTACUS_PIN_HOST=1: registrations owned by this call (PinRegistry); not worth their system calls
     // for small block calls (SPARTACUS_PIN_HOST_MIN_COLUMNS, default 4096)
     {
+      // Call-owned locks are the DEFAULT for calls of 32768 columns and more (measured on this box: locking
+      // and releasing ~1 GB per call costs ~1 ms from the second call on, the pipeline it enables takes 27 ->
+      // 17 ms off a 200 000-column call); SPARTACUS_PIN_HOST=1 lowers the threshold to
+      // SPARTACUS_PIN_HOST_MIN_COLUMNS (default 4096), SPARTACUS_PIN_HOST=0 switches locking off.
       const char* pe = std::getenv("SPARTACUS_PIN_HOST");
       const char* me = std::getenv("SPARTACUS_PIN_HOST_MIN_COLUMNS");
-      const int min_cols = me ? std::atoi(me) : 4096;
-      if (pe && pe[0] != '0' && c_end - c_begin >= min_cols) {
+      const bool off = pe && pe[0] == '0';
+      const int min_cols = me ? std::atoi(me) : (pe ? 4096 : 32768);
+      if (!off && c_end - c_begin >= min_cols) {
         pins_made = true;
         pin_call_arrays(config, canopy, sw, lw, bc_out, fl, c_begin, c_end, call_l0, call_l1);
       }
@@ -1073,9 +1105,22 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
     std::vector<double*> col_dev(col_out.size());
     for (size_t i = 0; i < col_out.size(); ++i)
       col_dev[i] = g_host.arena_get(col_out[i].name, (size_t)col_out[i].width * (size_t)(c_end - c_begin));
+    // per-layer outputs: call-level device arrays too - the sub-plans write their chunk's layer range of them,
+    // and they come home in copies that do NOT follow the chunking: one per member for every group of chunks
+    // (the download engine starts ~30 us late on every copy; 34 members x 7 chunks of such gaps were a third
+    // of a pinned 200 000-column call)
+    const std::vector<ColumnOutput> lay_out = layer_outputs(config, profiles, fl);
+    std::vector<double*> lay_dev(lay_out.size());
+    for (size_t i = 0; i < lay_out.size(); ++i)
+      lay_dev[i] = g_host.arena_get(lay_out[i].name, (size_t)lay_out[i].width * (size_t)std::max<long>(1, call_l1 - call_l0));
+    long lay_home = call_l0;       // layers [call_l0, lay_home) are on their way to the host (or there)
+    const char* de = std::getenv("SPARTACUS_HOST_DL_EVERY");
+    const int dl_every = de ? std::max(1, std::atoi(de)) : 1;
+    long col_home = c_begin;       // columns [c_begin, col_home): per-column members on their way to the host
+    int chunks_since_download = 0;
     constexpr int NS = HostEntry::kSlots;
     ChunkView views[NS];
-    bool inflight[NS] = {};     // results of the slot's chunk still on their way to the host
+    bool inflight[NS] = {};     // kernels of the slot's chunk may still be running
     int r = SS_OK;
     auto fail = [&](HipPlan* p, int code) {
       if (p) g_last_error = p->error;
@@ -1092,10 +1137,9 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
       const int c1 = std::min(c_end, c0 + chunk), s = k % NS;
       const double ta = now();
       HipPlan*& p = g_host.slot[s];
-      if (inflight[s]) {          // the chunk NS back used this slot: its results must be home first
-        r = p->download_end();
+      if (inflight[s]) {          // the chunk NS back used this slot: its kernels must be done before its inputs are replaced
+        p->be.sync();
         inflight[s] = false;
-        if (r) return fail(p, r);
       }
       const double tw = now();
       ChunkView& v = views[s];
@@ -1106,6 +1150,12 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
       for (size_t i = 0; i < col_out.size(); ++i)
         p->bind_external(col_out[i].name, col_dev[i] + (size_t)col_out[i].width * (size_t)(c0 - c_begin),
                          (size_t)col_out[i].width * (size_t)(c1 - c0));
+      long chunk_l0, chunk_l1;
+      layer_range(canopy, c0, c1, &chunk_l0, &chunk_l1);
+      if (chunk_l1 <= chunk_l0) chunk_l0 = chunk_l1 = lay_home;
+      for (size_t i = 0; i < lay_out.size(); ++i)
+        p->bind_external(lay_out[i].name, lay_dev[i] + (size_t)lay_out[i].width * (size_t)(chunk_l0 - call_l0),
+                         (size_t)lay_out[i].width * (size_t)std::max<long>(1, chunk_l1 - chunk_l0));
       if (fresh) {
         // one stream per sub-plan: the two sub-plans then sit on two hardware queues of their own, and
         // what this entry has to hide is PCIe time, not the (shorter) kernel time
@@ -1131,12 +1181,24 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
       r = p->solve();
       if (r) return fail(p, r);
       const double td = now();
-      // the results come back as soon as the kernels are done; the host does not wait here
-      // (the per-layer members of this chunk; the per-column ones wait in the call-level arrays)
-      auto fll_of = [](ChunkView& vv, int kk) { return vv.have_fl[kk] ? &vv.fl_layers[kk] : nullptr; };
-      r = p->download_begin(nullptr, fll_of(v, 0), fll_of(v, 1), fll_of(v, 2), fll_of(v, 3));
-      if (r) return fail(p, r);
       inflight[s] = true;
+      // The per-layer results of the chunks solved so far come home behind this chunk's kernels: after the
+      // first chunk (the download engine must start early), then for every second chunk and for the last.
+      ++chunks_since_download;
+      const bool last = c1 >= c_end;
+      if (k == 0 || chunks_since_download >= dl_every || last) {
+        const long upto = std::max(lay_home, chunk_l1);
+        if (upto > lay_home) {
+          hipStream_t ds = p->be.gate_downloads();      // the download stream waits for everything queued on this plan's stream
+          for (size_t i = 0; i < lay_out.size(); ++i) {
+            const size_t w = (size_t)lay_out[i].width;
+            HipBackend::copy_async(lay_out[i].host + w * (size_t)lay_home, lay_dev[i] + w * (size_t)(lay_home - call_l0),
+                                   w * (size_t)(upto - lay_home) * sizeof(double), hipMemcpyDeviceToHost, ds);
+          }
+          lay_home = upto;
+        }
+        chunks_since_download = 0;
+      }
       if (timing)
         std::fprintf(stderr, "host entry chunk %d (%d cols): wait for slot %.2f, view+upload %.2f, seed %.2f, solve queued %.2f, download queued %.2f ms\n",
                      k, c1 - c0, tw - ta, tb - tw, tc - tb, td - tc, now() - td);
@@ -1144,18 +1206,22 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
     for (int s = 0; s < NS; ++s) {
       if (!inflight[s]) continue;
       const double te = now();
-      r = g_host.slot[s]->download_end();
-      if (r) return fail(g_host.slot[s], r);
-      if (timing) std::fprintf(stderr, "host entry: slot %d home after %.2f ms\n", s, now() - te);
+      g_host.slot[s]->be.sync();
+      if (timing) std::fprintf(stderr, "host entry: slot %d done after %.2f ms\n", s, now() - te);
     }
-    // every kernel of the call has completed: the per-column outputs, one copy per member
+    // every kernel of the call has completed: the per-column outputs, one copy per member.  (Measured, 200 000
+    // columns: sending them with every chunk - 27 more ~1 MB copies per download point - 17.1 -> 20.2 ms; once
+    // at two thirds of the call and once at the end 18.7 ms; all at the end 17.3 ms.  Likewise the per-layer
+    // members: with every chunk 17.3, every second 17.5, every third 18.1, all at the end 22.3 ms: the transfer
+    // is bound by the bytes, ~45 GB/s down while ~30 GB/s go up, not by the number of copies.)
     {
       const double te = now();
       hipStream_t ds = g_host.down ? g_host.down : nullptr;
-      const size_t ncols = (size_t)(c_end - c_begin);
-      for (size_t i = 0; i < col_out.size(); ++i)
-        HipBackend::copy_async(col_out[i].host + (size_t)col_out[i].width * (size_t)c_begin, col_dev[i],
-                               (size_t)col_out[i].width * ncols * sizeof(double), hipMemcpyDeviceToHost, ds);
+      for (size_t i = 0; i < col_out.size(); ++i) {
+        const size_t w = (size_t)col_out[i].width;
+        HipBackend::copy_async(col_out[i].host + w * (size_t)col_home, col_dev[i] + w * (size_t)(col_home - c_begin),
+                               w * (size_t)(c_end - col_home) * sizeof(double), hipMemcpyDeviceToHost, ds);
+      }
       HIP_CHECK_THROW(hipStreamSynchronize(ds));
       if (timing) std::fprintf(stderr, "host entry: %zu per-column members home after %.2f ms\n", col_out.size(), now() - te);
     }
