@@ -250,10 +250,12 @@ int spartacus_radsurf_hip(const ss_config *config, const ss_canopy *canopy,
  * the whole run: pin once after allocation, unpin before deallocation.  A range
  * that partly overlaps an existing lock is refused (SS_ERR_HIP).
  *
- * SPARTACUS_PIN_HOST=1 (environment): the CALL owns the locks - spartacus_radsurf_hip
- * locks the slices of [istartcol, iendcol] it is handed on entry and releases
- * them before it returns (calls below SPARTACUS_PIN_HOST_MIN_COLUMNS, default
- * 4096, columns are not worth it).  Safe with any allocation pattern. */
+ * Call-owned locks (the default for calls of 32768 columns and more): spartacus_radsurf_hip
+ * locks the slices of [istartcol, iendcol] it is handed on entry and releases them
+ * before it returns - safe with any allocation pattern, nothing survives the call.
+ * SPARTACUS_PIN_HOST=1 lowers the threshold to SPARTACUS_PIN_HOST_MIN_COLUMNS (default
+ * 4096) columns, SPARTACUS_PIN_HOST=0 switches the locking off (every copy is then
+ * staged by the runtime and blocks the calling thread). */
 int ss_host_pin(const void *ptr, int64_t bytes);
 int ss_host_unpin(const void *ptr);
 int ss_host_unpin_all(void);
