@@ -9,7 +9,9 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -585,7 +587,7 @@ struct HostEntry {
   }
   ss_config cfg;
   int profiles = -1, device = -1;
-  long creations = 0;       // sub-plans built so far (tests: block calls must not re-create)
+  std::atomic<long> creations{0};   // sub-plans built so far, small-call slots included (tests: block calls must not re-create)
 
   void streams() {
     if (!up) HIP_CHECK_THROW(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
@@ -812,6 +814,114 @@ int next_chunk_columns(int total, int previous, bool pinned) {
   int c = previous > 0 ? std::max(16384, total / 6) : std::max(8192, total / 16);
   c = std::min(c, 131072);
   return ((c + 63) / 64) * 64;
+}
+
+// ---- small calls: the driver's block loop ----
+//
+// The reference's driver calls radsurf from OpenMP threads with blocks of nblocksize = 16 columns
+// (driver/spartacus_surface_driver.F90:206-234, driver/spartacus_surface_config.F90:25).  Through the
+// chunk pipeline above such a call is ~70 blocking copies of a few hundred bytes (1.9 ms: 8e3 columns/s,
+// five times slower than the reference on the host cores), and one mutex made the threads queue up.
+// Calls of up to kSmallColumns columns take this path instead:
+//  * a pool of kSlots sub-plans, each with a stream, a device slab and a page-locked host slab of its own
+//    and a mutex of its own: concurrent callers work on different slots at the same time (the entry-level
+//    lock is shared among them; large calls and re-configurations take it exclusively);
+//  * every output member of the call is a slice of the slot's device slab, so the results come home in
+//    ONE copy into the page-locked mirror and are scattered into the caller's arrays by the calling thread.
+struct SmallSlot {
+  std::mutex mu;
+  HipPlan* plan = nullptr;
+  double* slab = nullptr;       // device
+  double* hslab = nullptr;      // page-locked host mirror
+  size_t cap = 0;               // elements of both
+  void ensure(size_t elems) {
+    if (elems <= cap) return;
+    if (slab) hipFree(slab);
+    if (hslab) hipHostFree(hslab);
+    slab = hslab = nullptr;
+    cap = 0;
+    const size_t n = std::max<size_t>(elems * 2, 1 << 16);
+    HIP_CHECK_THROW(hipMalloc(reinterpret_cast<void**>(&slab), n * sizeof(double)));
+    HIP_CHECK_THROW(hipMemset(slab, 0, n * sizeof(double)));
+    HIP_CHECK_THROW(hipHostMalloc(reinterpret_cast<void**>(&hslab), n * sizeof(double), hipHostMallocDefault));
+    cap = n;
+  }
+  void drop() {
+    delete plan;
+    plan = nullptr;
+    if (slab) hipFree(slab);
+    if (hslab) hipHostFree(hslab);
+    slab = hslab = nullptr;
+    cap = 0;
+  }
+};
+struct SmallPool {
+  static constexpr int kSlots = 8;
+  SmallSlot slot[kSlots];
+  std::atomic<unsigned> next{0};
+  ss_config cfg;
+  int profiles = -1, device = -1;
+  bool matches(const ss_config* c, int prof, int dev) const {
+    return profiles == prof && device == dev && std::memcmp(&cfg, c, sizeof(ss_config)) == 0;
+  }
+};
+SmallPool g_small;                 // never destroyed at process exit (HIP may be gone)
+std::shared_mutex g_entry_mutex;   // shared: small calls; exclusive: large calls, (re)configuration of the pool
+constexpr int kSmallColumns = 2048;
+
+int small_call(SmallSlot& sl, const ss_config* config, const ss_canopy* canopy, const ss_sw_spectral* sw,
+               const ss_lw_spectral* lw, ss_bc_out* bc_out, int c_begin, int c_end, ss_flux* const* fl, int profiles) {
+  ChunkView v;
+  make_view(canopy, sw, lw, bc_out, fl, config->nsw, config->nlw, c_begin, c_end, v);
+  long l0, l1;
+  layer_range(canopy, c_begin, c_end, &l0, &l1);
+  const std::vector<ColumnOutput> col_out = column_outputs(config, profiles, bc_out, fl);
+  const std::vector<ColumnOutput> lay_out = layer_outputs(config, profiles, fl);
+  const size_t ncols = (size_t)(c_end - c_begin), nlays = (size_t)(l1 - l0);
+  // layout of the slab: every member at an even element (16-byte pairs)
+  std::vector<size_t> off(col_out.size() + lay_out.size() + 1, 0);
+  for (size_t i = 0; i < col_out.size(); ++i) off[i + 1] = off[i] + (((size_t)col_out[i].width * ncols + 1) & ~(size_t)1);
+  for (size_t i = 0; i < lay_out.size(); ++i) {
+    const size_t j = col_out.size() + i;
+    off[j + 1] = off[j] + (((size_t)lay_out[i].width * std::max<size_t>(1, nlays) + 1) & ~(size_t)1);
+  }
+  const size_t total = off.back();
+  sl.ensure(total);
+  const bool fresh = !sl.plan;
+  if (fresh) sl.plan = new HipPlan;
+  HipPlan* p = sl.plan;
+  p->unbind_externals();
+  for (size_t i = 0; i < col_out.size(); ++i)
+    p->bind_external(col_out[i].name, sl.slab + off[i], (size_t)col_out[i].width * ncols);
+  for (size_t i = 0; i < lay_out.size(); ++i)
+    p->bind_external(lay_out[i].name, sl.slab + off[col_out.size() + i], (size_t)lay_out[i].width * std::max<size_t>(1, nlays));
+  int r;
+  if (fresh) {
+    p->pipes_cap = 1;          // everything of a slot on its one stream, in order: no events between streams
+    ++g_host.creations;
+    r = p->create(config, &v.can, sw ? &v.sw : nullptr, lw ? &v.lw : nullptr, 1, c_end - c_begin, profiles);
+  } else {
+    r = p->reset(&v.can, sw ? &v.sw : nullptr, lw ? &v.lw : nullptr, 1, c_end - c_begin, false);
+  }
+  if (r) { g_last_error = p->error; return r; }
+  auto fl_of = [&](int k) { return v.have_fl[k] ? &v.fl[k] : nullptr; };
+  const bool always_seed = std::getenv("SPARTACUS_ALWAYS_SEED") != nullptr;
+  p->upload_outputs(&v.bc, fl_of(0), fl_of(1), fl_of(2), fl_of(3), always_seed ? (int)HipPlan::SEED_ALL : p->seed_needed());
+  r = p->solve();
+  if (r) { g_last_error = p->error; return r; }
+  hipStream_t st = p->be.stream();
+  HIP_CHECK_THROW(hipMemcpyAsync(sl.hslab, sl.slab, total * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIP_CHECK_THROW(hipStreamSynchronize(st));
+  for (size_t i = 0; i < col_out.size(); ++i) {
+    const size_t w = (size_t)col_out[i].width;
+    std::memcpy(col_out[i].host + w * (size_t)c_begin, sl.hslab + off[i], w * ncols * sizeof(double));
+  }
+  if (nlays > 0)
+    for (size_t i = 0; i < lay_out.size(); ++i) {
+      const size_t w = (size_t)lay_out[i].width;
+      std::memcpy(lay_out[i].host + w * (size_t)l0, sl.hslab + off[col_out.size() + i], w * nlays * sizeof(double));
+    }
+  return SS_OK;
 }
 
 }  // namespace
@@ -1048,8 +1158,61 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
     return SS_ERR_BAD_ARGUMENT;
   }
   if (iendcol < istartcol) return SS_OK;
-  // The reference is called concurrently on disjoint column ranges
-  // (spartacus_surface_driver.F90:206-233); one device: serialise.
+  // The reference is called concurrently on disjoint column ranges (spartacus_surface_driver.F90:206-233).
+  // Small calls - its default blocks of 16 columns - run side by side on the slots of g_small ...
+  {
+    const char* se = std::getenv("SPARTACUS_SMALL_CALL_COLUMNS");
+    const int small_max = se ? std::atoi(se) : kSmallColumns;
+    if (iendcol - istartcol + 1 <= small_max) {
+      const int profiles = ((sw_norm_dir && sw_norm_dir->flux_dn_layer_top)
+                            || (lw_internal && lw_internal->flux_dn_layer_top)) ? 1 : 0;
+      int device = 0;
+      if (!hip_ok(hipGetDevice(&device), "hipGetDevice")) return SS_ERR_HIP;
+      ss_flux* fls[4] = {config->do_sw ? sw_norm_dir : nullptr, config->do_sw ? sw_norm_diff : nullptr,
+                         config->do_lw ? lw_internal : nullptr, config->do_lw ? lw_norm : nullptr};
+      for (;;) {
+        {
+          std::shared_lock<std::shared_mutex> shared(g_entry_mutex);
+          if (g_small.matches(config, profiles, device)) {
+            // a free slot (one that already holds a plan first: a sequential caller stays on one slot), else queue up
+            SmallSlot* sl = nullptr;
+            std::unique_lock<std::mutex> own;
+            for (int pass = 0; pass < 2 && !sl; ++pass)
+              for (int i = 0; i < SmallPool::kSlots && !sl; ++i) {
+                if (pass == 0 && !g_small.slot[i].plan) continue;
+                std::unique_lock<std::mutex> t(g_small.slot[i].mu, std::try_to_lock);
+                if (t.owns_lock()) { sl = &g_small.slot[i]; own = std::move(t); }
+              }
+            if (!sl) {
+              sl = &g_small.slot[g_small.next++ % SmallPool::kSlots];
+              own = std::unique_lock<std::mutex>(sl->mu);
+            }
+            const int rcs = guarded([&]() -> int {
+              try {
+                return small_call(*sl, config, canopy, sw, lw, bc_out, istartcol - 1, iendcol, fls, profiles);
+              } catch (...) {
+                if (sl->plan) { try { sl->plan->be.sync(); } catch (...) {} }
+                sl->drop();
+                throw;
+              }
+            });
+            if (rcs != SS_OK && sl->plan) { try { sl->plan->be.sync(); } catch (...) {} sl->drop(); }
+            return rcs;
+          }
+        }
+        // (re)configure the pool: exclusive
+        std::unique_lock<std::shared_mutex> excl(g_entry_mutex);
+        if (!g_small.matches(config, profiles, device)) {
+          for (auto& sl : g_small.slot) { std::lock_guard<std::mutex> l(sl.mu); sl.drop(); }
+          g_small.cfg = *config;
+          g_small.profiles = profiles;
+          g_small.device = device;
+        }
+      }
+    }
+  }
+  // ... large calls have the device to themselves.
+  std::unique_lock<std::shared_mutex> entry_lock(g_entry_mutex);
   std::lock_guard<std::mutex> lock(g_device_mutex);
   bool pins_made = false;
   // Whatever happens inside, the entry does not return while the device may still touch the caller's

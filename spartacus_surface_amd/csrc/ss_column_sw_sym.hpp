@@ -57,16 +57,17 @@ SS_HD void sw_ground(const LG& lg, double ga, double gad, double cos_sza, const 
 
 // One layer: consumes R^, T^ (packed), S_up^, S_dn^ (rows scaled), E of the layer record; stores P, Q, a_below,
 // d_below UNSCALED into the column record; returns a_below^ (packed) and d_below^ (rows scaled).
-template <int N, int D>
-SS_HD void sw_adding_step(const double* lrec, const double* Aab, const double* Dab, double* crec,
+// src: the layer record in HBM (RecSource) or what the fused layer stage left in LDS / registers (FusedSource)
+template <int N, int D, class Src>
+SS_HD void sw_adding_step(const Src& src, const double* Aab, const double* Dab, double* crec,
                           const double* dsc, const double* rd, double* Abe, double* Dbe) {
   using LRec = SwLayRec<N, D>;
   using CRec = SwColRec<N, D>;
   static_assert(LRec::PACKED && !CRec::PACKED, "packed layer record, full column record");
   constexpr long st = kRecStride;
   double R[rec_even(kTri<N>)], T[rec_even(kTri<N>)];
-  rec_load<rec_even(kTri<N>)>(lrec, st, LRec::R, R);
-  rec_load<rec_even(kTri<N>)>(lrec, st, LRec::T, T);
+  src.template load<rec_even(kTri<N>)>(LRec::R, R);
+  src.template load<rec_even(kTri<N>)>(LRec::T, T);
   SS_LOAD_FENCE(); SS_SCHED_FENCE();
   // denominator = I - a_above^ R^
   double Den[N * N];
@@ -126,8 +127,8 @@ SS_HD void sw_adding_step(const double* lrec, const double* Aab, const double* D
   rec_store<N * N>(crec, st, CRec::ABE, X);
   // d_below^ = S_up^ + T^ Den^-1 (d_above^ E + a_above^ S_dn^);  Q^ = Den^-1 (R^ (d_above^ E) + S_dn^)
   double E[D * D], S[N * D], Y[N * D];
-  rec_load<D * D>(lrec, st, LRec::EDIR, E);
-  rec_load<N * D>(lrec, st, LRec::SDN, S);
+  src.template load<D * D>(LRec::EDIR, E);
+  src.template load<N * D>(LRec::SDN, S);
   mat_mul<N, D, D>(Dab, E, Y);
   {
     double Q[N * D];
@@ -160,7 +161,7 @@ SS_HD void sw_adding_step(const double* lrec, const double* Aab, const double* D
     }
   }
   lu_solve_mat<N, D>(Den, Y);
-  rec_load<N * D>(lrec, st, LRec::SUP, S);
+  src.template load<N * D>(LRec::SUP, S);
   SS_UNROLL_FULL
   for (int j = 0; j < D; ++j) {
     SS_UNROLL_FULL
@@ -309,7 +310,7 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
   }
   sym::sw_ground<NREG, NS>(L.lg, in.ground_albedo[c.cidx], in.ground_albedo_dir[c.cidx], c.cos_sza, rsf, Aab, Dab);
   for (int jlay = 0; jlay < c.nlay; ++jlay) {
-    const double* lrec = L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu);
+    const RecSource lrec{L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu), kRecStride};
     double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
     double dsc[N], rd[N];
     SS_UNROLL_FULL
@@ -330,6 +331,57 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
   sym::sw_top_albedos<NREG, NS>(L, c.cidx, c.cos_sza, Aab, Dab);
 }
 
+// Layer matrices AND adding step of every layer of a column unit on one lane (k_layer_up), both in the scaled
+// coordinates: the layer unit writes R^, T^ (2 x 22 slots) and S_up^, S_dn^ (2 x 18) into the lane's 80 LDS
+// slots - the whole packed layer record up to E -, E stays in registers and goes, with int_dir, to the column
+// record for the downward sweep; the adding step reads them back from LDS element by element.  No layer
+// record exists.  a_above^ / d_above^ are carried across the layer stage by the compiler (VGPRs, or AGPRs as
+// first-level spill space at one wave per SIMD).
+template <bool URBAN, int NREG, int NS>
+SS_HD void layer_up_sw(const Launch& L, int cu) {
+  constexpr int N = NREG * NS, D = NREG;
+  using LRec = SwLayRec<N, D>;
+  using CRec = SwColRec<N, D>;
+  static_assert(CRec::FUSED && LRec::PACKED && LRec::EDIR <= kLaneLdsSlots, "R^, T^, S_up^, S_dn^ must fit the lane's LDS slots");
+  using Lds = LaneLds<true>;
+  const Inputs& in = L.in;
+  const SwColCtx<URBAN, NREG, NS> c(L, cu, false);
+  const Lds lds{};
+  double Aab[kTri<N>], Dab[N * D];
+  double sf[NREG], rsf[NREG];
+  {
+    double vf = 0.0, bf = 0.0, frac[NREG];
+    if (c.nlay > 0) pack_fractions(pack_rec(L, 0, cu, kPackSw), vf, bf);
+    region_fractions<URBAN, false, NREG>(vf, bf, frac);
+    region_roots<NREG>(frac, sf, rsf);
+  }
+  sym::sw_ground<NREG, NS>(L.lg, in.ground_albedo[c.cidx], in.ground_albedo_dir[c.cidx], c.cos_sza, rsf, Aab, Dab);
+  for (int jlay = 0; jlay < c.nlay; ++jlay) {
+    double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
+    double hold[LRec::IDIR - LRec::EDIR];       // E
+    const FusedWriter<LRec::EDIR, LRec::IDIR, LRec::EDIR, CRec::EDIR, Lds> w{
+        &lds, hold, crec, kRecStride, (unsigned long long*)L.eigen_fail};
+    layer_unit_sw<URBAN, NREG, NS>(L, cu, jlay, w);
+    double dsc[N], rd[N];
+    SS_UNROLL_FULL
+    for (int r = 0; r < NREG; ++r) {
+      SS_UNROLL_FULL
+      for (int s = 0; s < NS; ++s) {
+        dsc[s + r * NS] = sf[r] * L.lg.sqrt_wmu[s];
+        rd[s + r * NS] = rsf[r] * L.lg.rsqrt_wmu[s];
+      }
+    }
+    const FusedSource<LRec::EDIR, Lds> src{&lds, hold};
+    double Abe[kTri<N>], Dbe[N * D];
+    sym::sw_adding_step<N, D>(src, Aab, Dab, crec, dsc, rd, Abe, Dbe);
+    double sfu[NREG], rsfu[NREG];
+    sym::sw_overlap_above<URBAN, NREG, NS>(L, cu, jlay, c.nlay, c.cos_sza, Abe, Dbe, sf, rsf, sfu, rsfu, Aab, Dab);
+    SS_UNROLL_FULL
+    for (int r = 0; r < NREG; ++r) { sf[r] = sfu[r]; rsf[r] = rsfu[r]; }
+  }
+  sym::sw_top_albedos<NREG, NS>(L, c.cidx, c.cos_sza, Aab, Dab);
+}
+
 }  // namespace sym
 
 // The upward sweep of one column unit (k_column): in symmetrised coordinates where the layer record is packed
@@ -340,9 +392,16 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
 }
 
 // Whole column on one lane (host emulation and small problems)
+// layer + upward sweep on one lane (k_layer_up): scaled coordinates where the layer record is packed
+template <bool URBAN, int NREG, int NS>
+SS_HD void layer_up_sw_any(const Launch& L, int cu) {
+  if constexpr (SwLayRec<NREG * NS, NREG>::PACKED) sym::layer_up_sw<URBAN, NREG, NS>(L, cu);
+  else layer_up_sw<URBAN, NREG, NS>(L, cu);
+}
+
 template <bool URBAN, int NREG, int NS>
 SS_HD void column_unit_sw(const Launch& L, int cu) {
-  if constexpr (SwColRec<NREG * NS, NREG>::FUSED) layer_up_sw<URBAN, NREG, NS>(L, cu);
+  if constexpr (SwColRec<NREG * NS, NREG>::FUSED) layer_up_sw_any<URBAN, NREG, NS>(L, cu);
   else column_up_sw<URBAN, NREG, NS>(L, cu);
   column_down_sw<URBAN, NREG, NS>(L, cu, 0);
   column_down_sw<URBAN, NREG, NS>(L, cu, 1);

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(kBlock, 1) k_layer_up(const Launch L) {
   if (cu >= L.ncu) return;
   if constexpr (fused_order(R * NS, LW)) {
     if constexpr (LW) layer_up_lw<U, R, NS>(L, cu);
-    else layer_up_sw<U, R, NS>(L, cu);
+    else layer_up_sw_any<U, R, NS>(L, cu);
   }
 }
 

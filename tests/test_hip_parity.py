@@ -94,6 +94,32 @@ def test_golden_host_entry(path):
     assert not bad, "outside the parity bar: %s" % bad[:5]
 
 
+@pytest.mark.parametrize("name", ["simple__test_surfaces", "simple__test_overhang", "urban__2stream", "urban__4stream",
+                                  "rami4pilps__vis-med-0.3", "extra__ragged-tiles", "extra__single_layer-mixed",
+                                  "single_layer__sp"])
+def test_golden_host_entry_chunk_pipeline(name, monkeypatch):
+    """Calls of up to 2048 columns take the entry's small-call path (a slot of their own, one slab download);
+    the same goldens through the chunk pipeline of the large calls (SPARTACUS_SMALL_CALL_COLUMNS=0), in
+    chunks of 8 columns where the case has that many."""
+    radsurf = _hip()
+    have = [p for p in golden_files() if os.path.basename(p)[:-4] == name]
+    if not have:
+        pytest.skip("fixture not present")
+    monkeypatch.setenv("SPARTACUS_SMALL_CALL_COLUMNS", "0")
+    monkeypatch.setenv("SPARTACUS_HOST_CHUNK", "8")
+    case, expected = fixture_io.load_case(have[0])
+    cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
+    if case["do_simple_spectrum"]:
+        from spartacus_surface_amd.inputs import calc_simple_spectrum_lw
+        calc_simple_spectrum_lw(cfg, cp, lw)
+    out = _alloc(case)
+    radsurf.radsurf(cfg, cp, sw, lw, out["bc_out"], 1, cp.ncol, out["sw_norm_dir"],
+                    out["sw_norm_diff"], out["lw_internal"], out["lw_norm"])
+    bad = fixture_io.parity_violations(fixture_io.flatten_outputs(out), expected, dict(case["ref_noise"]),
+                                       truth=case["ref_truth"], noise_arr=case["ref_noise_arr"])
+    assert not bad, "outside the parity bar: %s" % bad[:5]
+
+
 @pytest.mark.parametrize("name", ["urban__4stream", "rami5__HET07_JPS_SUM-56-direct", "rami4pilps__vis-snw-0.3-2-4",
                                   "extra__urban-5stream"])
 def test_golden_with_cooperative_route_declined(name, monkeypatch):
@@ -400,6 +426,8 @@ def test_host_entry_chunks_blocks_and_seeding(monkeypatch):
         base = _host_entry(radsurf, case, _sentinel_outputs(case))
         monkeypatch.delenv("SPARTACUS_ALWAYS_SEED")
         lean = _host_entry(radsurf, case, _sentinel_outputs(case))
+        # the chunk pipeline of the large calls (the small-call path switched off), forced into small chunks
+        monkeypatch.setenv("SPARTACUS_SMALL_CALL_COLUMNS", "0")
         monkeypatch.setenv("SPARTACUS_HOST_CHUNK", "96")
         chunked = _host_entry(radsurf, case, _sentinel_outputs(case))
         monkeypatch.delenv("SPARTACUS_HOST_CHUNK")
@@ -407,12 +435,20 @@ def test_host_entry_chunks_blocks_and_seeding(monkeypatch):
         out = _sentinel_outputs(case)
         ncol = case["canopy"].ncol
         for i0 in range(1, ncol + 1, 16):
+            blocks_big = _host_entry(radsurf, case, out, i0, min(ncol, i0 + 15))
+        assert radsurf.host_entry_plan_creations() == n0, "block calls re-created the device plans"
+        # ... and the same blocks through the small-call path (a slot with a slab of its own)
+        monkeypatch.delenv("SPARTACUS_SMALL_CALL_COLUMNS")
+        n0 = radsurf.host_entry_plan_creations()
+        out = _sentinel_outputs(case)
+        for i0 in range(1, ncol + 1, 16):
             blocks = _host_entry(radsurf, case, out, i0, min(ncol, i0 + 15))
         assert radsurf.host_entry_plan_creations() == n0, "block calls re-created the device plans"
         for k, v in base.items():
             assert np.array_equal(v, lean[k]), ("seed", k)
             assert np.array_equal(v, chunked[k]), ("chunk", k)
-            assert np.array_equal(v, blocks[k]), ("blocks", k)
+            assert np.array_equal(v, blocks_big[k]), ("blocks, chunk pipeline", k)
+            assert np.array_equal(v, blocks[k]), ("blocks, small-call path", k)
 
 
 def test_plan_follows_its_device_and_streams_are_per_plan():
