@@ -253,6 +253,19 @@ def roofline_block(fam_ms, fam_n, nsteps, columns, case, pmc, evidence, ms_per_s
             rl["achieved"] = fl * cols_per_launch / (avg_ms * 1e-3) / 1e12
             rl["frac"] = rl["achieved"] / FP64_PEAK_TFLOPS
             rl["flops_per_column_executed_by_this_kernel"] = fl
+        # every kernel family of the step against both ceilings (serial durations; traffic and flops of the
+        # committed PMC summary): the layer kernels sit at the fp64 issue ceiling, the sweeps at the HBM one
+        table = {}
+        for k in fam_ms:
+            if fam_n[k] == 0 or fam_ms[k] <= 0.0:
+                continue
+            sec = fam_ms[k] / nsteps * 1e-3
+            f64 = pmc["fp64_flops_per_column_executed"].get(k, 0.0) * columns / sec / 1e12
+            hbm = tb.get(k, 0.0) * columns / sec / 1e9
+            table[k] = {"ms_per_step": 1e3 * sec, "fp64_TFLOPs": f64, "fp64_frac": f64 / FP64_PEAK_TFLOPS,
+                        "traffic_GBs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS,
+                        "nearer_ceiling": "fp64" if f64 / FP64_PEAK_TFLOPS >= hbm / HBM_PEAK_GBS else "hbm"}
+        rl["kernels"] = table
     return rl
 
 

@@ -192,9 +192,10 @@ SS_HD void lw_top(const Launch& L, long cidx, const double* Aab, const double* S
   L.top2[cidx] = s;                 // top_emission
 }
 
-// The upward sweep as a kernel of its own (k_column; orders above SS_UNROLL_MAX)
+// The upward sweep in the reference's (unscaled) coordinates: orders whose records are not packed
+// (k_column dispatches in ss_column_lw_sym.hpp)
 template <bool URBAN, int NREG, int NS>
-SS_HD void column_up_lw(const Launch& L, int cu) {
+SS_HD void column_up_lw_full(const Launch& L, int cu) {
   constexpr int N = NREG * NS;
   using LRec = LwLayRec<N>;
   using CRec = LwColRec<N>;
@@ -348,16 +349,17 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
   constexpr long st = kRecStride;
   const Inputs& in = L.in;
   const LG& lg = L.lg;
-  // a_below of a layer from the column record: packed and scaled for the small orders (vf, bf: the layer's fractions)
-  auto load_abe = [&](const double* crec_, double vf_, double bf_, double* ABE_) {
+  // a_below of a layer: the column record holds it packed and scaled for the small orders; NABE doubles are
+  // loaded as they lie and applied through abe_matvec (vf, bf: the fractions of the layer it belongs to)
+  constexpr int NABE = CRec::PACKED ? rec_even(tri_count(N)) : N * N;
+  auto abe_matvec = [&](const double* ABE_, double vf_, double bf_, const double* x_, double* y_) {
     if constexpr (CRec::PACKED) {
       double frac_[NREG], dsc_[N], rd_[N];
       region_fractions<URBAN, true, NREG>(vf_, bf_, frac_);
       layer_scaling<NREG, NS>(lg, frac_, dsc_, rd_);
-      const RecSource src_{crec_, st};
-      load_packed_unscaled<N>(src_, CRec::ABE, dsc_, rd_, ABE_);
+      packed_scaled_matvec<N>(ABE_, dsc_, rd_, x_, y_);
     } else {
-      rec_load<N * N>(crec_, st, CRec::ABE, ABE_);
+      mat_vec<N, N>(ABE_, x_, y_);
     }
   };
   const int col = L.cols[cu / L.nspec];
@@ -406,7 +408,7 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
     interface_overlap_vals<URBAN, true, NREG>(L.cfg.min_vegetation_fraction, upper_is_sky, vf_up, bf_up,
                                               false, dlo.g.veg_fraction, dlo.g.building_fraction, U, V);
     apply_V_vec<NREG, DB, NS>(V, dn_ab, dn_below);
-    mat_vec<N, N>(ABE, dn_below, up_below);
+    abe_matvec(ABE, dlo.g.veg_fraction, dlo.g.building_fraction, dn_below, up_below);
     SS_UNROLL_N(N)
     for (int i = 0; i < N; ++i) up_below[i] = up_below[i] + src * SBE[i];
     if (URBAN) {
@@ -431,9 +433,9 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
   if (nlay > 0) {
     const int jlay = nlay - 1;
     const double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
-    double ABE[N * N], SBE[N];
+    double ABE[NABE], SBE[N];
     din.load_pack(pack_rec(L, jlay, cu, kPackLw));
-    load_abe(crec, din.g.veg_fraction, din.g.building_fraction, ABE);
+    rec_load<NABE>(crec, st, CRec::ABE, ABE);
     rec_load<N>(crec, st, CRec::SBE, SBE);
     SS_LOAD_FENCE();
     cross(din, true, 0.0, 0.0, ABE, SBE, dn_above, dn_below, up_below, nullptr);
@@ -464,11 +466,11 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
     }
 
     // ---- issue group 3 (a_below, source_below and the scalars of the layer below), work on group 2 ----
-    double ABE[N * N], SBE[N];
+    double ABE[NABE], SBE[N];
     if (jlay > 0) {
       const double* crec_n = L.col + rec_base(jlay - 1, L.maxlay, CRec::NELEM, cu);
       din.load_pack(pack_rec(L, jlay - 1, cu, kPackLw));
-      load_abe(crec_n, din.g.veg_fraction, din.g.building_fraction, ABE);
+      rec_load<NABE>(crec_n, st, CRec::ABE, ABE);
       rec_load<N>(crec_n, st, CRec::SBE, SBE);
     }
     SS_LOAD_FENCE();
@@ -625,16 +627,6 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
 #undef PUTC
 #undef PUTL
 #undef FSEL
-}
-
-// Whole column on one lane (host emulation and small problems)
-template <bool URBAN, int NREG, int NS>
-SS_HD void column_unit_lw(const Launch& L, int cu) {
-  double slot = 0.0;
-  if constexpr (LwColRec<NREG * NS>::FUSED) layer_up_lw<URBAN, NREG, NS>(L, cu);
-  else column_up_lw<URBAN, NREG, NS>(L, cu);
-  column_down_lw<URBAN, NREG, NS>(L, cu, 0, &slot);
-  column_down_lw<URBAN, NREG, NS>(L, cu, 1, &slot);
 }
 
 }  // namespace ss

@@ -414,16 +414,17 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
   const Inputs& in = L.in;
   const LG& lg = L.lg;
   const SwColCtx<URBAN, NREG, NS> c(L, cu, true);
-  // a_below of a layer from the column record: packed and scaled for the small orders (vf, bf: the layer's fractions)
-  auto load_abe = [&](const double* crec_, double vf_, double bf_, double* ABE_) {
+  // a_below of a layer: the column record holds it packed and scaled for the small orders; NABE doubles are
+  // loaded as they lie and applied through abe_matvec (vf, bf: the fractions of the layer it belongs to)
+  constexpr int NABE = CRec::PACKED ? rec_even(tri_count(N)) : N * N;
+  auto abe_matvec = [&](const double* ABE_, double vf_, double bf_, const double* x_, double* y_) {
     if constexpr (CRec::PACKED) {
       double frac_[NREG], dsc_[N], rd_[N];
       region_fractions<URBAN, false, NREG>(vf_, bf_, frac_);
       layer_scaling<NREG, NS>(lg, frac_, dsc_, rd_);
-      const RecSource src_{crec_, st};
-      load_packed_unscaled<N>(src_, CRec::ABE, dsc_, rd_, ABE_);
+      packed_scaled_matvec<N>(ABE_, dsc_, rd_, x_, y_);
     } else {
-      rec_load<N * N>(crec_, st, CRec::ABE, ABE_);
+      mat_vec<N, N>(ABE_, x_, y_);
     }
   };
   const int col = c.col, jb = c.jb, nspec = c.nspec, nlay = c.nlay, l0 = c.l0, itransp = c.itransp;
@@ -486,7 +487,7 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
       dir_below[jl] = acc;
     }
     apply_V_vec<NREG, DB, NS>(V, diff_ab, diff_below);
-    mat_vec<N, N>(ABE, diff_below, up_below);
+    abe_matvec(ABE, lo[0], lo[1], diff_below, up_below);
     mat_vec_acc<N, D>(DBE, dir_below, up_below);
     if (URBAN) {
       // exposed roof (urban :717-721): a_below / d_below roof blocks
@@ -511,9 +512,9 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
   if (nlay > 0) {
     const int jlay = nlay - 1;
     const double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
-    double ABE[N * N], DBE[N * D];
+    double ABE[NABE], DBE[N * D];
     din.load_pack(pack_rec(L, jlay, cu, kPackSw));
-    load_abe(crec, din.g.veg_fraction, din.g.building_fraction, ABE);
+    rec_load<NABE>(crec, st, CRec::ABE, ABE);
     rec_load<N * D>(crec, st, CRec::DBE, DBE);
     SS_LOAD_FENCE();
     const double lo[4] = {din.g.veg_fraction, din.g.building_fraction, din.roof_albedo, din.roof_albedo_dir};
@@ -573,7 +574,7 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
     mat_vec<N, D>(Q, dir_below, t3);
 
     // ---- issue group 4 (a_below, d_below and the scalars of the layer below; int_dir), work on group 3 ----
-    double ABE[N * N], DBE[N * D], IDIR[D * D];
+    double ABE[NABE], DBE[N * D], IDIR[D * D];
     double lo[4] = {0.0, 0.0, 0.0, 0.0};
     if (jlay > 0) {
       const double* crec_n = L.col + rec_base(jlay - 1, L.maxlay, CRec::NELEM, cu);
@@ -582,7 +583,7 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
       const RecPair ra = rec_pair_load(pn + 8 * kRecStride);   // roof_albedo, roof_albedo_dir
       lo[2] = ra.x;
       lo[3] = ra.y;
-      load_abe(crec_n, lo[0], lo[1], ABE);
+      rec_load<NABE>(crec_n, st, CRec::ABE, ABE);
       rec_load<N * D>(crec_n, st, CRec::DBE, DBE);
     }
     if (CRec::FUSED) rec_load<D * D>(crec, st, CRec::IDIR, IDIR);

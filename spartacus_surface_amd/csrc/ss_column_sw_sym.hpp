@@ -63,7 +63,7 @@ SS_HD void sw_adding_step(const Src& src, const double* Aab, const double* Dab, 
                           const double* dsc, const double* rd, double* Abe, double* Dbe) {
   using LRec = SwLayRec<N, D>;
   using CRec = SwColRec<N, D>;
-  static_assert(LRec::PACKED && !CRec::PACKED, "packed layer record, full column record");
+  static_assert(LRec::PACKED, "packed layer record");
   constexpr long st = kRecStride;
   double R[rec_even(kTri<N>)], T[rec_even(kTri<N>)];
   src.template load<rec_even(kTri<N>)>(LRec::R, R);
@@ -118,13 +118,21 @@ SS_HD void sw_adding_step(const Src& src, const double* Aab, const double* Dab, 
       Abe[lo<N>(i, j)] = s;
     }
   }
-  // ... stored unscaled and full: a_below = D a_below^ D^-1 (X is free)
-  SS_UNROLL_FULL
-  for (int j = 0; j < N; ++j) {
+  if constexpr (CRec::PACKED) {
+    // ... stored as it is: packed and scaled (the downward sweep applies it as D (a_below^ (D^-1 x)))
+    static_loop<0, rec_even(kTri<N>) / 2>([&](auto pc) {
+      constexpr int e = 2 * decltype(pc)::value;
+      rec_pair_store(crec + (long)(CRec::ABE + e) * st, Abe[e], (e + 1 < kTri<N>) ? Abe[e + 1 < kTri<N> ? e + 1 : 0] : 0.0);
+    });
+  } else {
+    // ... stored unscaled and full: a_below = D a_below^ D^-1 (X is free)
     SS_UNROLL_FULL
-    for (int i = 0; i < N; ++i) SS_E(X, i, j, N) = (dsc[i] * rd[j]) * Abe[sy<N>(i, j)];
+    for (int j = 0; j < N; ++j) {
+      SS_UNROLL_FULL
+      for (int i = 0; i < N; ++i) SS_E(X, i, j, N) = (dsc[i] * rd[j]) * Abe[sy<N>(i, j)];
+    }
+    rec_store<N * N>(crec, st, CRec::ABE, X);
   }
-  rec_store<N * N>(crec, st, CRec::ABE, X);
   // d_below^ = S_up^ + T^ Den^-1 (d_above^ E + a_above^ S_dn^);  Q^ = Den^-1 (R^ (d_above^ E) + S_dn^)
   double E[D * D], S[N * D], Y[N * D];
   src.template load<D * D>(LRec::EDIR, E);

@@ -88,10 +88,14 @@ constexpr bool sym_packed(int nf, bool lw) {
   return nf >= 3 && nf <= SS_UNROLL_MAX && (lw || true);
 #endif
 }
-// Column record (a_below): packed and scaled for the longwave (layer 3.29 -> 3.12, upward sweep 3.11 -> 2.83,
-// downward 2.58 -> 2.42 ms per step with both packings); the shortwave downward sweep reads it unscaled (with
-// the packed form it went 4.13 -> 4.41).
+// Column record (a_below): packed and scaled.  The downward sweeps apply it to their flux vector as
+// D (a_below^ (D^-1 x)) without restoring the matrix (packed_scaled_matvec): restoring it into 36 doubles first
+// was measured on the shortwave sweep and costs more than the bytes save (4.13 -> 4.41 ms per step).
+#if defined(SS_NO_SYM_PACK_COL_SW)
 constexpr bool sym_packed_col(int nf, bool lw) { return lw && sym_packed(nf, lw); }
+#else
+constexpr bool sym_packed_col(int nf, bool lw) { return sym_packed(nf, lw); }
+#endif
 constexpr int tri_count(int n) { return n * (n + 1) / 2; }
 // packed lower triangle, column by column: index of (i, j), i >= j, and back
 constexpr int tri_index(int n, int i, int j) { return i + j * n - j * (j + 1) / 2; }
@@ -389,6 +393,22 @@ SS_HD void store_packed_scaled(double* rec, long stride, int off, const double* 
       v1 = SS_E(X, i1, j1, N) * (dsc[j1] * rd[i1]);
     }
     rec_pair_store(rec + (long)(off + E) * stride, SS_E(X, i0, j0, N) * (dsc[j0] * rd[i0]), v1);
+  });
+}
+// y = D X^ D^-1 x for a packed symmetric X^ (the product with the unscaled matrix without restoring it)
+template <int N>
+SS_HD void packed_scaled_matvec(const double* Xp, const double* dsc, const double* rd, const double* x, double* y) {
+  double t[N];
+  SS_UNROLL_FULL
+  for (int k = 0; k < N; ++k) t[k] = rd[k] * x[k];
+  static_loop<0, N>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    double acc = 0.0;
+    static_loop<0, N>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      acc += Xp[tri_index(N, i >= k ? i : k, i >= k ? k : i)] * t[k];
+    });
+    y[i] = dsc[i] * acc;
   });
 }
 // scaling of the components of a layer: dsc = sqrt(region fraction) x sqrt(weight mu), rd = 1 / dsc

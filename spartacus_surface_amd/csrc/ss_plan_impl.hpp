@@ -41,6 +41,7 @@
 #include "ss_column_lw.hpp"
 #include "ss_column_sw.hpp"
 #include "ss_column_sw_sym.hpp"
+#include "ss_column_lw_sym.hpp"
 #include "ss_solver_lw.hpp"
 #include "ss_solver_sw.hpp"
 
