@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py - canopy columns/s of the SPARTACUS-Surface SW+LW column solver on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c3ns4|c4|c4ns4|rami5] [--scaling weak|strong]
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c2|c2r3ns8|c3ns4|c4|c4ns4|rami5] [--scaling weak|strong]
 
 A "step" is one pass of the hot path (radsurf: layer kernels + column kernels,
 SW and LW) over one batch of synthetic columns that is already resident in HBM.
@@ -63,6 +63,7 @@ def flops_per_column(case):
 
 WORKLOAD_NAMES = {
     "c2": "C2: test/rami4pilps forest SW (vis-med-0.3), 2 regions x 1 stream x 2 layers, 1 band",
+    "c2r3ns8": "C2 column set run as test/rami4pilps method '-2-8': forest SW, 3 regions x 8 streams (n = 24) x 2 layers, 1 band",
     "c3": "C3: test/urban vegetated-urban SW+LW, 3 regions x 2 streams x 10 layers, 1 SW + 1 LW band",
     "c3ns4": "C3 with 4 streams: vegetated-urban SW+LW, 3 regions x 4 streams x 10 layers (n = 12)",
     "c4": "C4: mixed forest / vegetated-urban SW+LW, 3 regions x 2 streams x 10 layers, 14 SW + 16 LW bands",
@@ -77,6 +78,8 @@ def make_case(workload, ncol, seed):
     from spartacus_surface_amd import workloads
     if workload == "c2":
         return workloads.c2_rami4pilps(ncol=ncol)
+    if workload == "c2r3ns8":
+        return workloads.c2_rami4pilps(ncol=ncol, nstream=8, n_vegetation_region=2)
     if workload == "c3ns4":
         return workloads.c3_vegetated_urban(ncol=ncol, seed=seed, nstream=4)
     if workload == "c4":
@@ -403,7 +406,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--columns", type=int, default=1_000_000,
                     help="columns per GPU (weak scaling) or in total (strong scaling)")
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c3ns4", "c4", "c4ns4", "rami5"],
+    ap.add_argument("--workload", default="c3", choices=["c2", "c2r3ns8", "c3", "c3ns4", "c4", "c4ns4", "rami5"],
                     help="c3 (default) is the headline configuration; the others are extra lines")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --columns per GPU; strong: --columns in total, sharded over the GPUs "

@@ -41,6 +41,10 @@
 #define SS_UNROLL_N(N) SS_PRAGMA(unroll((N) <= SS_UNROLL_MAX ? (N) : 1))
 #define SS_UNROLL_NN(N) SS_PRAGMA(unroll((N) <= SS_UNROLL_MAX ? (N) * (N) : 1))
 #define SS_UNROLL_FULL SS_PRAGMA(unroll)
+// Loops of the symmetric routines (ss_layer_sym.hpp, ss_eigen_sym.hpp), which serve the register-resident orders
+// AND, with rolled loops and their matrices in scratch, the orders above 16: full unrolling up to SS_UNROLL_MAX
+// (no trip count exceeds N * N there), none beyond
+#define SS_SYM_UNROLL(N) SS_PRAGMA(unroll((N) <= SS_UNROLL_MAX ? (N) * (N) : 1))
 
 // Compiler-level fence that keeps the memory accesses written before it before
 // it in the instruction stream (no hardware wait): used to issue a whole group

@@ -37,19 +37,19 @@ namespace ss {
 template <int N>
 SS_HD void sym_tridiagonalise(double* a, double* d, double* e) {
 #define A_(i, j) a[(i) + (j) * N]
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int i = N - 1; i >= 1; --i) {
     const int l = i - 1;
     double h = 0.0;
     if (l > 0) {
       double scale = 0.0;
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int k = 0; k <= l; ++k) scale += fabs(A_(i, k));
       if (scale == 0.0) {
         e[i] = A_(i, l);
       } else {
         const double rs = 1.0 / scale;
-        SS_UNROLL_FULL
+        SS_SYM_UNROLL(N)
         for (int k = 0; k <= l; ++k) {
           A_(i, k) *= rs;
           h += A_(i, k) * A_(i, k);
@@ -61,24 +61,24 @@ SS_HD void sym_tridiagonalise(double* a, double* d, double* e) {
         A_(i, l) = f - g;
         f = 0.0;
         const double rh = 1.0 / h;
-        SS_UNROLL_FULL
+        SS_SYM_UNROLL(N)
         for (int j = 0; j <= l; ++j) {
           A_(j, i) = A_(i, j) * rh;
           g = 0.0;
-          SS_UNROLL_FULL
+          SS_SYM_UNROLL(N)
           for (int k = 0; k <= j; ++k) g += A_(j, k) * A_(i, k);
-          SS_UNROLL_FULL
+          SS_SYM_UNROLL(N)
           for (int k = j + 1; k <= l; ++k) g += A_(k, j) * A_(i, k);
           e[j] = g * rh;
           f += e[j] * A_(i, j);
         }
         const double hh = f / (h + h);
-        SS_UNROLL_FULL
+        SS_SYM_UNROLL(N)
         for (int j = 0; j <= l; ++j) {
           f = A_(i, j);
           g = e[j] - hh * f;
           e[j] = g;
-          SS_UNROLL_FULL
+          SS_SYM_UNROLL(N)
           for (int k = 0; k <= j; ++k) A_(j, k) -= f * e[k] + g * A_(i, k);
         }
       }
@@ -89,22 +89,22 @@ SS_HD void sym_tridiagonalise(double* a, double* d, double* e) {
   }
   d[0] = 0.0;
   e[0] = 0.0;
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int i = 0; i < N; ++i) {
     const int l = i - 1;
     if (d[i] != 0.0) {
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int j = 0; j <= l; ++j) {
         double g = 0.0;
-        SS_UNROLL_FULL
+        SS_SYM_UNROLL(N)
         for (int k = 0; k <= l; ++k) g += A_(i, k) * A_(k, j);
-        SS_UNROLL_FULL
+        SS_SYM_UNROLL(N)
         for (int k = 0; k <= l; ++k) A_(k, j) -= g * A_(k, i);
       }
     }
     d[i] = A_(i, i);
     A_(i, i) = 1.0;
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int j = 0; j <= l; ++j) {
       A_(j, i) = 0.0;
       A_(i, j) = 0.0;
@@ -121,10 +121,10 @@ template <int N>
 SS_HD int sym_tridiagonal_ql(double* d, double* e, double* z) {
 #define Z_(i, j) z[(i) + (j) * N]
   int ierr = 0;
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int i = 1; i < N; ++i) e[i - 1] = e[i];
   e[N - 1] = 0.0;
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int l = 0; l < N; ++l) {
     int iter = 0;
     for (;;) {
@@ -132,7 +132,7 @@ SS_HD int sym_tridiagonal_ql(double* d, double* e, double* z) {
       int m = N - 1;
       {
         bool found = false;
-        SS_UNROLL_FULL
+        SS_SYM_UNROLL(N)
         for (int mm = l; mm < N - 1; ++mm) {
           if (!found) {
             const double dd = fabs(d[mm]) + fabs(d[mm + 1]);
@@ -148,12 +148,12 @@ SS_HD int sym_tridiagonal_ql(double* d, double* e, double* z) {
       double r = sqrt(g * g + 1.0);
       // d[m] with run-time m
       double dm = 0.0;
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int k = l; k < N; ++k) dm = (k == m) ? d[k] : dm;
       g = dm - d[l] + e[l] / (g + ss_sign(r, g));
       double s = 1.0, c = 1.0, p = 0.0;
       bool broke = false;
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int i = N - 2; i >= l; --i) {
         if (i <= m - 1 && !broke) {
           double f = s * e[i];
@@ -163,7 +163,7 @@ SS_HD int sym_tridiagonal_ql(double* d, double* e, double* z) {
           if (r == 0.0) {
             d[i + 1] -= p;
             // e[m] = 0
-            SS_UNROLL_FULL
+            SS_SYM_UNROLL(N)
             for (int k = l; k < N; ++k) e[k] = (k == m) ? 0.0 : e[k];
             broke = true;
           } else {
@@ -175,7 +175,7 @@ SS_HD int sym_tridiagonal_ql(double* d, double* e, double* z) {
             p = s * r;
             d[i + 1] = g + p;
             g = c * r - b;
-            SS_UNROLL_FULL
+            SS_SYM_UNROLL(N)
             for (int k = 0; k < N; ++k) {
               f = Z_(k, i + 1);
               Z_(k, i + 1) = s * Z_(k, i) + c * f;
@@ -187,7 +187,7 @@ SS_HD int sym_tridiagonal_ql(double* d, double* e, double* z) {
       if (!broke) {
         d[l] -= p;
         e[l] = g;
-        SS_UNROLL_FULL
+        SS_SYM_UNROLL(N)
         for (int k = l; k < N; ++k) e[k] = (k == m) ? 0.0 : e[k];
       }
     }
@@ -206,7 +206,7 @@ template <int N>
 SS_HD int eigen_decomposition_gamma_sym(const double* A, const double* G2, const double* dscale,
                                         double* eigenvalue, double* eigenvector, double* ainv_x) {
   double rd[N];
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int i = 0; i < N; ++i) {
     if (!(dscale[i] > 0.0)) return -1;
     rd[i] = 1.0 / dscale[i];
@@ -215,9 +215,9 @@ SS_HD int eigen_decomposition_gamma_sym(const double* A, const double* G2, const
   // from the lower: the rounding-level asymmetry is dropped), and the symmetry check
   double C[N * N], M[N * N];
   double asym = 0.0, size = 0.0;
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int j = 0; j < N; ++j) {
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = j; i < N; ++i) {
       const double c_ij = -SS_E(A, i, j, N) * (dscale[j] * rd[i]);
       const double s_ij = SS_E(G2, i, j, N) * (dscale[j] * rd[i]);
@@ -237,19 +237,19 @@ SS_HD int eigen_decomposition_gamma_sym(const double* A, const double* G2, const
   // Cholesky C = L L^T (L in the lower triangle of C, reciprocal diagonal in rl)
   double rl[N];
   bool ok = true;
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int j = 0; j < N; ++j) {
     double s = SS_E(C, j, j, N);
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int k = 0; k < j; ++k) s -= SS_E(C, j, k, N) * SS_E(C, j, k, N);
     if (!(s > 1.0e-14 * size)) ok = false;
     const double ljj = sqrt(ok ? s : 1.0);
     SS_E(C, j, j, N) = ljj;
     rl[j] = 1.0 / ljj;
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = j + 1; i < N; ++i) {
       double t = SS_E(C, i, j, N);
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int k = 0; k < j; ++k) t -= SS_E(C, i, k, N) * SS_E(C, j, k, N);
       SS_E(C, i, j, N) = t * rl[j];
     }
@@ -257,22 +257,22 @@ SS_HD int eigen_decomposition_gamma_sym(const double* A, const double* G2, const
   if (!ok) return -1;
   // K = L^T M L  (W = M L, then K = L^T W; K symmetric, lower triangle computed)
   double W[N * N], K[N * N];
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int j = 0; j < N; ++j) {
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = 0; i < N; ++i) {
       double s = 0.0;
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int k = j; k < N; ++k) s += SS_E(M, i, k, N) * SS_E(C, k, j, N);
       SS_E(W, i, j, N) = s;
     }
   }
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int j = 0; j < N; ++j) {
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = j; i < N; ++i) {
       double s = 0.0;
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int k = i; k < N; ++k) s += SS_E(C, k, i, N) * SS_E(W, k, j, N);
       SS_E(K, i, j, N) = s;
       SS_E(K, j, i, N) = s;
@@ -282,20 +282,20 @@ SS_HD int eigen_decomposition_gamma_sym(const double* A, const double* G2, const
   sym_tridiagonalise<N>(K, eigenvalue, e);
   const int ierr = sym_tridiagonal_ql<N>(eigenvalue, e, K);
   // eigenvectors of P: X = D L Y;   A^-1 X = -D L^-T Y (back-substitution with L^T)
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int j = 0; j < N; ++j) {
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = 0; i < N; ++i) {
       double s = 0.0;
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int k = 0; k <= i; ++k) s += SS_E(C, i, k, N) * SS_E(K, k, j, N);
       SS_E(eigenvector, i, j, N) = dscale[i] * s;
     }
     double v[N];
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = N - 1; i >= 0; --i) {
       double s = SS_E(K, i, j, N);
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int k = i + 1; k < N; ++k) s -= SS_E(C, k, i, N) * v[k];
       v[i] = s * rl[i];
       SS_E(ainv_x, i, j, N) = -dscale[i] * v[i];
@@ -316,7 +316,7 @@ SS_HD int eigen_decomposition_gamma_sym(const double* A, const double* G2, const
 template <int N>
 SS_HD bool sym_spectrum_is_well_graded(const double* ev) {
   double lo = fabs(ev[0]), hi = fabs(ev[0]);
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int i = 1; i < N; ++i) {
     lo = ss_min(lo, fabs(ev[i]));
     hi = ss_max(hi, fabs(ev[i]));
@@ -334,16 +334,16 @@ template <int N>
 SS_HD int eigen_decomposition_scaled_sym(const double* G, const double* dscale, double* eigenvalue,
                                          double* eigenvector) {
   double rd[N];
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int i = 0; i < N; ++i) {
     if (!(dscale[i] > 0.0)) return -1;
     rd[i] = 1.0 / dscale[i];
   }
   double K[N * N];
   double asym = 0.0, size = 0.0;
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int j = 0; j < N; ++j) {
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = j; i < N; ++i) {
       const double k_ij = SS_E(G, i, j, N) * (dscale[j] * rd[i]);
       if (i != j) asym = ss_max(asym, fabs(k_ij - SS_E(G, j, i, N) * (dscale[i] * rd[j])));
@@ -356,9 +356,9 @@ SS_HD int eigen_decomposition_scaled_sym(const double* G, const double* dscale, 
   double e[N];
   sym_tridiagonalise<N>(K, eigenvalue, e);
   const int ierr = sym_tridiagonal_ql<N>(eigenvalue, e, K);
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int j = 0; j < N; ++j) {
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = 0; i < N; ++i) SS_E(eigenvector, i, j, N) = dscale[i] * SS_E(K, i, j, N);
   }
   return ierr;

@@ -69,6 +69,16 @@ struct LwRec {
   static constexpr int NELEM = ISRC + rec_even(NF);
 };
 
+// orders above those of the row-of-16 kernels (3 regions x 7 or 8 streams): the symmetrised route with rolled
+// loops and its matrices in scratch memory, in place of the general eigen-solver (-DSS_NO_SYM_SCRATCH: off)
+constexpr bool sym_scratch_order(int n) {
+#if defined(SS_NO_SYM_SCRATCH) || defined(SS_NO_SYM_LAYER)
+  return false && n > 0;
+#else
+  return n > 16;   // kCoopMaxOrder of ss_eigen_coop.hpp
+#endif
+}
+
 // Layer records of the solver pipeline.  Orders whose layer matrices are computed in symmetrised coordinates
 // (3 <= NF <= SS_UNROLL_MAX: ss_layer_sym.hpp) store R^ = D^-1 R D and T^ = D^-1 T D - symmetric by
 // reciprocity - as packed lower triangles, NF (NF + 1) / 2 doubles instead of NF^2 (n = 6: the shortwave

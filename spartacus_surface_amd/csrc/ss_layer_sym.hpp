@@ -63,20 +63,20 @@ SS_HD void sqrt_rsqrt(double x, double& s, double& rs) {
 template <int N>
 SS_HD bool cholesky(double* A, double* rd, double size) {
   bool ok = true;
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int j = 0; j < N; ++j) {
     double s = A[lo<N>(j, j)];
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int k = 0; k < j; ++k) s -= A[lo<N>(j, k)] * A[lo<N>(j, k)];
     if (!(s > 1.0e-14 * size)) ok = false;
     double ljj, rl;
     sqrt_rsqrt(ok ? s : 1.0, ljj, rl);
     A[lo<N>(j, j)] = ljj;
     rd[j] = rl;
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = j + 1; i < N; ++i) {
       double t = A[lo<N>(i, j)];
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int k = 0; k < j; ++k) t -= A[lo<N>(i, k)] * A[lo<N>(j, k)];
       A[lo<N>(i, j)] = t * rl;
     }
@@ -87,20 +87,20 @@ SS_HD bool cholesky(double* A, double* rd, double size) {
 // x := L^-1 x, x := L^-T x (L packed lower with reciprocal diagonal rd)
 template <int N>
 SS_HD void solve_L(const double* L, const double* rd, double* x) {
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int i = 0; i < N; ++i) {
     double s = x[i];
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int k = 0; k < i; ++k) s -= L[lo<N>(i, k)] * x[k];
     x[i] = s * rd[i];
   }
 }
 template <int N>
 SS_HD void solve_LT(const double* L, const double* rd, double* x) {
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int i = N - 1; i >= 0; --i) {
     double s = x[i];
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int k = i + 1; k < N; ++k) s -= L[lo<N>(k, i)] * x[k];
     x[i] = s * rd[i];
   }
@@ -109,10 +109,10 @@ SS_HD void solve_LT(const double* L, const double* rd, double* x) {
 // y = S x for a packed symmetric S
 template <int N>
 SS_HD void symv(const double* S, const double* x, double* y) {
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int i = 0; i < N; ++i) {
     double s = 0.0;
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int k = 0; k < N; ++k) s += S[sy<N>(i, k)] * x[k];
     y[i] = s;
   }
@@ -121,15 +121,15 @@ SS_HD void symv(const double* S, const double* x, double* y) {
 // Z (packed) = X diag(f) X^T for a full N x N matrix X (column-major)
 template <int N>
 SS_HD void rank_update(const double* X, const double* f, double* Z) {
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int i = 0; i < N; ++i) {
     double xf[N];
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int k = 0; k < N; ++k) xf[k] = SS_E(X, i, k, N) * f[k];
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int j = 0; j <= i; ++j) {
       double s = 0.0;
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int k = 0; k < N; ++k) s += xf[k] * SS_E(X, j, k, N);
       Z[lo<N>(i, j)] = s;
     }
@@ -141,48 +141,48 @@ SS_HD void rank_update(const double* X, const double* f, double* Z) {
 template <int N>
 SS_HD void inverse_of_identity_plus(double* Z) {
   double rd[N];
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int j = 0; j < N; ++j) Z[lo<N>(j, j)] += 1.0;
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int j = 0; j < N; ++j) {
     double s = Z[lo<N>(j, j)];
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int k = 0; k < j; ++k) s -= Z[lo<N>(j, k)] * Z[lo<N>(j, k)];
     double ljj, rl;
     sqrt_rsqrt(s, ljj, rl);
     rd[j] = rl;
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = j + 1; i < N; ++i) {
       double t = Z[lo<N>(i, j)];
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int k = 0; k < j; ++k) t -= Z[lo<N>(i, k)] * Z[lo<N>(j, k)];
       Z[lo<N>(i, j)] = t * rl;
     }
   }
   // Q = R^-1 (lower), column by column: Q(j,j) = 1/R(j,j), Q(i,j) = -Q(i,i) sum_{k=j}^{i-1} R(i,k) Q(k,j)
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int j = 0; j < N; ++j) {
     double q[N];
     q[j] = rd[j];
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = j + 1; i < N; ++i) {
       double s = 0.0;
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int k = j; k < i; ++k) s += Z[lo<N>(i, k)] * q[k];
       q[i] = -s * rd[i];
     }
     // column j of R is not needed by the later columns of Q (they use rows i > j', k >= j' > j)
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = j; i < N; ++i) Z[lo<N>(i, j)] = q[i];
   }
   // (I + Z)^-1 = Q^T Q: element (i, j), i >= j, = sum_{k >= i} Q(k,i) Q(k,j); rows top to bottom in place
   // (element (i, j) reads Q(k, .) with k >= i only, and of row i itself the entries not yet overwritten)
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int j = 0; j < N; ++j) {
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = j; i < N; ++i) {
       double s = 0.0;
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int k = i; k < N; ++k) s += Z[lo<N>(k, i)] * Z[lo<N>(k, j)];
       Z[lo<N>(i, j)] = s;
     }
@@ -196,15 +196,15 @@ template <int N>
 SS_HD double build_CM(const double* GD, const double* G2, const double* dscale, double* C, double* M) {
   double rd[N];
   bool ok = true;
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int i = 0; i < N; ++i) {
     if (!(dscale[i] > 0.0)) ok = false;
     rd[i] = 1.0 / dscale[i];
   }
   double asym = 0.0, size = 0.0;
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int j = 0; j < N; ++j) {
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = j; i < N; ++i) {
       const double c_ij = -SS_E(GD, i, j, N) * (dscale[j] * rd[i]);
       const double s_ij = SS_E(G2, i, j, N) * (dscale[j] * rd[i]);
@@ -236,20 +236,20 @@ SS_HD int spectral(double* C, double* rl, const double* M, double size, double* 
   if (!cholesky<N>(C, rl, size)) return -1;
   // K = L^T M L column by column: t = M L(:, j), K(i, j) = L(:, i)^T t for i >= j (tred2 reads the lower triangle)
   double* K = AiT;      // the eigenvectors, then A^-T, replace K in place
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int j = 0; j < N; ++j) {
     double t[N];
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = 0; i < N; ++i) {
       double s = 0.0;
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int k = j; k < N; ++k) s += M[sy<N>(i, k)] * C[lo<N>(k, j)];
       t[i] = s;
     }
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = j; i < N; ++i) {
       double s = 0.0;
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int k = i; k < N; ++k) s += C[lo<N>(k, i)] * t[k];
       SS_E(K, i, j, N) = s;
       SS_E(K, j, i, N) = s;
@@ -282,43 +282,58 @@ SS_HD int spectral(double* C, double* rl, const double* M, double size, double* 
   // direct mode of a transparent layer has mu^2 inside the cluster of tiny eigenvalues.
   // The permutation is data dependent, so it goes through the lane's LDS slots (N^2 <= 36 of them).
   int rank[N];
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int i = 0; i < N; ++i) {
     int r = 0;
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int j = 0; j < N; ++j) {
       const double di = SS_E(K, i, i, N), dj = SS_E(K, j, j, N);
       if (j != i && (dj < di || (dj == di && j < i))) ++r;
     }
     rank[i] = r;
   }
-  SS_UNROLL_FULL
-  for (int j = 0; j < N; ++j) {
-    SS_UNROLL_FULL
-    for (int i = 0; i < N; ++i) lds.put(rank[i] + rank[j] * N, SS_E(K, i, j, N));
+  if constexpr (N * N <= Lds::kSlots) {
+    SS_SYM_UNROLL(N)
+    for (int j = 0; j < N; ++j) {
+      SS_SYM_UNROLL(N)
+      for (int i = 0; i < N; ++i) lds.put(rank[i] + rank[j] * N, SS_E(K, i, j, N));
+    }
+    SS_SYM_UNROLL(N)
+    for (int k = 0; k < N * N; ++k) K[k] = lds.get(k);
+  } else {
+    // orders whose matrices live in scratch memory anyway (above 16): a copy takes the place of the LDS slots
+    double Kc[N * N];
+    for (int k = 0; k < N * N; ++k) Kc[k] = K[k];
+    for (int j = 0; j < N; ++j)
+      for (int i = 0; i < N; ++i) K[rank[i] + rank[j] * N] = Kc[i + j * N];
   }
-  SS_UNROLL_FULL
-  for (int k = 0; k < N * N; ++k) K[k] = lds.get(k);
   double e[N];
   sym_tridiagonalise<N>(K, ev, e);
   ierr = sym_tridiagonal_ql<N>(ev, e, K);
   // rows of the eigenvector matrix back into the solver's order
-  SS_UNROLL_FULL
-  for (int k = 0; k < N * N; ++k) lds.put(k, K[k]);
-  SS_UNROLL_FULL
-  for (int j = 0; j < N; ++j) {
-    SS_UNROLL_FULL
-    for (int i = 0; i < N; ++i) SS_E(K, i, j, N) = lds.get(rank[i] + j * N);
+  if constexpr (N * N <= Lds::kSlots) {
+    SS_SYM_UNROLL(N)
+    for (int k = 0; k < N * N; ++k) lds.put(k, K[k]);
+    SS_SYM_UNROLL(N)
+    for (int j = 0; j < N; ++j) {
+      SS_SYM_UNROLL(N)
+      for (int i = 0; i < N; ++i) SS_E(K, i, j, N) = lds.get(rank[i] + j * N);
+    }
+  } else {
+    double Kc[N * N];
+    for (int k = 0; k < N * N; ++k) Kc[k] = K[k];
+    for (int j = 0; j < N; ++j)
+      for (int i = 0; i < N; ++i) SS_E(K, i, j, N) = Kc[rank[i] + j * N];
   }
   }
   // The QL iteration has absolute accuracy eps * (largest eigenvalue): an eigenvalue far below that
   // (transparent, conservative layers: 13 decades) may come out as rounding noise of either sign.  A negative
   // eigenvalue that is NOT noise declines the unit.
   double evmax = 0.0;
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int j = 0; j < N; ++j) evmax = ss_max(evmax, ev[j]);
   bool pos = evmax > 0.0;
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int j = 0; j < N; ++j)
     if (!(ev[j] > -1.0e-10 * evmax)) pos = false;
   if (!pos) return -1;
@@ -327,25 +342,25 @@ SS_HD int spectral(double* C, double* rl, const double* M, double size, double* 
   // enters it squared, what is left is the rounding of M a, ~1e-17 absolute: eigenvalues 10 decades down keep
   // 6-8 digits.  They carry the absorption of a nearly conservative layer (reflect_transmit) and meet mu^2 of
   // the unattenuated direct mode in the particular solutions of the shortwave.
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int j = 0; j < N; ++j) {
     double y[N], a[N], ma[N];
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = 0; i < N; ++i) y[i] = SS_E(K, i, j, N);
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = 0; i < N; ++i) {
       double s = 0.0;
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int k = 0; k <= i; ++k) s += C[lo<N>(i, k)] * y[k];
       a[i] = s;
     }
     symv<N>(M, a, ma);
     double rq = 0.0;
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = 0; i < N; ++i) rq += a[i] * ma[i];
     ev[j] = ss_max(rq, 0.0);
     solve_LT<N>(C, rl, y);
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = 0; i < N; ++i) SS_E(AiT, i, j, N) = y[i];
   }
   return ierr;
@@ -355,17 +370,17 @@ SS_HD int spectral(double* C, double* rl, const double* M, double size, double* 
 template <int N>
 SS_HD void apply_C(const double* L, double* x) {
   double t[N];
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int k = 0; k < N; ++k) {
     double s = 0.0;
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = k; i < N; ++i) s += L[lo<N>(i, k)] * x[i];
     t[k] = s;
   }
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int i = 0; i < N; ++i) {
     double s = 0.0;
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int k = 0; k <= i; ++k) s += L[lo<N>(i, k)] * t[k];
     x[i] = s;
   }
@@ -395,7 +410,7 @@ template <int N, bool KEEP_PHI>
 SS_HD void impedances(const double* M, const double* L, const double* AiT, const double* ev, double h,
                       double* Wp, double* Wm, double* Phi) {
   double t[N], fm[N];
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int k = 0; k < N; ++k) {
     t[k] = h * phi_tanh(sqrt(ev[k]) * h);
     fm[k] = 1.0 / t[k];
@@ -405,20 +420,20 @@ SS_HD void impedances(const double* M, const double* L, const double* AiT, const
   double Psi[kTri<N>];
   rank_update<N>(AiT, t, Psi);
   // column j of Phi = C Psi(:, j); Z+(i, j) = M(i, :) Phi(:, j) for i >= j (symmetric in exact arithmetic)
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int j = 0; j < N; ++j) {
     double c[N];
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = 0; i < N; ++i) c[i] = Psi[sy<N>(i, j)];
     apply_C<N>(L, c);
     if constexpr (KEEP_PHI) {
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int i = 0; i < N; ++i) SS_E(Phi, i, j, N) = c[i];
     }
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = j; i < N; ++i) {
       double s = 0.0;
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int k = 0; k < N; ++k) s += M[sy<N>(i, k)] * c[k];
       Wp[lo<N>(i, j)] = s;
     }
@@ -442,16 +457,16 @@ SS_HD void put_reflect_transmit(const W& w, int offR, int offT, const double* Wp
     });
   } else {
     double t[N * N];
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int j = 0; j < N; ++j) {
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int i = 0; i < N; ++i)
         SS_E(t, i, j, N) = (dsc[i] * rd[j]) * (Wp[sy<N>(i, j)] + Wm[sy<N>(i, j)] - (i == j ? 1.0 : 0.0));
     }
     put_embedded<NF, NF, N, N, I0, I0>(w, offR, t);
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int j = 0; j < N; ++j) {
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int i = 0; i < N; ++i) SS_E(t, i, j, N) = (dsc[i] * rd[j]) * (Wp[sy<N>(i, j)] - Wm[sy<N>(i, j)]);
     }
     put_embedded<NF, NF, N, N, I0, I0>(w, offT, t);
@@ -476,10 +491,10 @@ SS_HD int calc_matrices_lw_sym(const double* g1, const double* g2, const double*
   double gh[N];
   {
     double F[kTri<N>], rf[N];
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int k = 0; k < kTri<N>; ++k) F[k] = M[k];
     if (!cholesky<N>(F, rf, size)) return -1;
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = 0; i < N; ++i) gh[i] = b[i] / dsc[i];
     solve_L<N>(F, rf, gh);
     solve_LT<N>(F, rf, gh);
@@ -490,7 +505,7 @@ SS_HD int calc_matrices_lw_sym(const double* g1, const double* g2, const double*
   double Wp[kTri<N>], Wm[kTri<N>], Phi[N * N];
   impedances<N, true>(M, C, AiT, ev, 0.5 * dz, Wp, Wm, Phi);
   double rd[N];
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int i = 0; i < N; ++i) rd[i] = 1.0 / dsc[i];
   put_reflect_transmit<NF, N, I0, Rec::PACKED>(w, Rec::R, Rec::T, Wp, Wm, dsc, rd);
   // source = 2 Z+ W+ g^ = 2 M (Phi (W+ g^)): the small numbers come from M
@@ -502,12 +517,12 @@ SS_HD int calc_matrices_lw_sym(const double* g1, const double* g2, const double*
   // integrated flux matrix IF = 2 M^-1 Z+ W+ = 2 Phi W+ and integrated source 2 (g^ dz - IF g^) = 2 (g^ dz - 2 Phi y)
   {
     double IF[N * N];
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int j = 0; j < N; ++j) {
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int i = 0; i < N; ++i) {
         double s2 = 0.0;
-        SS_UNROLL_FULL
+        SS_SYM_UNROLL(N)
         for (int k = 0; k < N; ++k) s2 += SS_E(Phi, i, k, N) * Wp[sy<N>(k, j)];
         SS_E(IF, i, j, N) = (2.0 * dsc[i] * rd[j]) * s2;
       }
@@ -543,7 +558,7 @@ SS_HD int calc_matrices_sw_sym(const double* g0, const double* g1, const double*
   double mu[D], G0[D * D], G0inv[D * D], emu[D];
   ierr += sw_direct_embedded<NF, DF, D, R0, Rec>(g0, dsc0, dz, w, mu, G0, G0inv, emu);
   double rd[N];
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int i = 0; i < N; ++i) rd[i] = 1.0 / dsc[i];
 
   // Particular solutions of the direct sources (sw_eig :231-253), one per direct eigenvalue mu, scaled: with
@@ -552,29 +567,29 @@ SS_HD int calc_matrices_sw_sym(const double* g0, const double* g1, const double*
   // (the eigenvalues are the Rayleigh quotients of spectral(): in a transparent layer the unattenuated direct
   // mode, mu^2 ~ 1e-10, meets eigenvalues of the same size in this division).  Kept: r (N per mode).
   double rv[N * D];
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int jd = 0; jd < D; ++jd) {
     double sh[N];
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = 0; i < N; ++i) {
       double t = 0.0;
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int k = 0; k < D; ++k) t += SS_E(g3, i, k, N) * SS_E(G0, k, jd, D);
       sh[i] = 2.0 * t * rd[i];
     }
     apply_C<N>(C, sh);
     double c[N];
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int k = 0; k < N; ++k) {
       double t = 0.0;
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int i = 0; i < N; ++i) t += SS_E(AiT, i, k, N) * sh[i];
       c[k] = t / (ev[k] - mu[jd] * mu[jd]);
     }
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = 0; i < N; ++i) {
       double s = 0.0;
-      SS_UNROLL_FULL
+      SS_SYM_UNROLL(N)
       for (int k = 0; k < N; ++k) s += SS_E(AiT, i, k, N) * c[k];
       SS_E(rv, i, jd, N) = s;
     }
@@ -587,14 +602,14 @@ SS_HD int calc_matrices_sw_sym(const double* g0, const double* g1, const double*
   //   S_up = g3 - R g4 - T g3 e = p - W+ x+ - W- x-,   S_dn = g4 e - T g4 - R g3 e = e p - W+ x+ + W- x-,
   //   x+ = g4 + g3 e,  x- = g4 - g3 e
   double su[N * D], sd[N * D];
-  SS_UNROLL_FULL
+  SS_SYM_UNROLL(N)
   for (int jd = 0; jd < D; ++jd) {
     double p[N], xp[N], xm[N], wp[N], wm[N];
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = 0; i < N; ++i) p[i] = SS_E(rv, i, jd, N);
     apply_C<N>(C, p);
     const double e = emu[jd];
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = 0; i < N; ++i) {
       const double q = mu[jd] * SS_E(rv, i, jd, N);
       const double g3h = 0.5 * (p[i] + q), g4h = 0.5 * (p[i] - q);
@@ -603,7 +618,7 @@ SS_HD int calc_matrices_sw_sym(const double* g0, const double* g1, const double*
     }
     symv<N>(Wp, xp, wp);
     symv<N>(Wm, xm, wm);
-    SS_UNROLL_FULL
+    SS_SYM_UNROLL(N)
     for (int i = 0; i < N; ++i) {
       // (rows scaled where the record is packed: the upward sweep then works in the scaled coordinates)
       const double un = Rec::PACKED ? 1.0 : dsc[i];

@@ -239,9 +239,14 @@ template <int NF, int N, int I0, bool GENERAL, class W>
 SS_HD int calc_matrices_lw_route(const double* g1, const double* g2, const double* b, const double* dsc, double dz,
                                  const W& w, const CoopEig* coop = nullptr) {
 #if !defined(SS_NO_SYM_LAYER)
-  if constexpr (!GENERAL && NF >= 3 && N <= SS_UNROLL_MAX) {
+  // the register-resident orders, and (rolled loops, matrices in scratch) the orders above those of the
+  // row-of-16 kernels: 3 regions x 8 streams = 24 - the general eigen-solver then only sees declined units
+  if constexpr (!GENERAL && NF >= 3 && (N <= SS_UNROLL_MAX || sym_scratch_order(N))) {
     int rc = -1;
-    if (dsc) rc = sym::calc_matrices_lw_sym<NF, N, I0>(g1, g2, b, dsc, dz, w, w.scratch());
+    if (dsc) {
+      if constexpr (N <= SS_UNROLL_MAX) rc = sym::calc_matrices_lw_sym<NF, N, I0>(g1, g2, b, dsc, dz, w, w.scratch());
+      else rc = sym::calc_matrices_lw_sym<NF, N, I0>(g1, g2, b, dsc, dz, w, LaneLds<false>{});
+    }
     // sub-problems of the orders above SS_UNROLL_MAX (second pass of the layer kernel, itself the slow
     // path): general route in line; the small orders hand the decline to their caller
     if (rc >= 0 || NF <= SS_UNROLL_MAX) return rc;

@@ -168,9 +168,14 @@ SS_HD int calc_matrices_sw_route(const double* g0, const double* g1, const doubl
                                  const double* dsc0, const double* dsc, double dz, const W& w,
                                  const CoopEig* coop = nullptr) {
 #if !defined(SS_NO_SYM_LAYER)
-  if constexpr (!GENERAL && NF >= 3 && N <= SS_UNROLL_MAX) {
+  // the register-resident orders, and (rolled loops, matrices in scratch) the orders above those of the
+  // row-of-16 kernels: 3 regions x 8 streams = 24 - the general eigen-solver then only sees declined units
+  if constexpr (!GENERAL && NF >= 3 && (N <= SS_UNROLL_MAX || sym_scratch_order(N))) {
     int rc = -1;
-    if (dsc) rc = sym::calc_matrices_sw_sym<NF, DF, N, D, I0, R0>(g0, g1, g2, g3, dsc0, dsc, dz, w, w.scratch());
+    if (dsc) {
+      if constexpr (N <= SS_UNROLL_MAX) rc = sym::calc_matrices_sw_sym<NF, DF, N, D, I0, R0>(g0, g1, g2, g3, dsc0, dsc, dz, w, w.scratch());
+      else rc = sym::calc_matrices_sw_sym<NF, DF, N, D, I0, R0>(g0, g1, g2, g3, dsc0, dsc, dz, w, LaneLds<false>{});
+    }
     if (rc >= 0 || NF <= SS_UNROLL_MAX) return rc;      // (see calc_matrices_lw_route)
   }
 #endif

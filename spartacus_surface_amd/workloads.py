@@ -73,14 +73,15 @@ def _finish(cfg, cp, sw, lw, **extra):
     return d
 
 
-def c2_rami4pilps(ncol=100_000):
+def c2_rami4pilps(ncol=100_000, nstream=1, n_vegetation_region=1):
     """C2: RAMI4PILPS open forest canopy, scenario vis-med-0.3
     (test/rami4pilps/Makefile:36, expand_args.sh): forest, SW only, 1 band,
     1 stream, 2 regions, 2 layers; the base column replicated with cos_sza
-    cycling through the 46 values of duplicate_profiles.sh:19."""
+    cycling through the 46 values of duplicate_profiles.sh:19.  nstream=8, n_vegetation_region=2 is the
+    method run "-2-8" of test/rami4pilps/Makefile:31-32 (3 regions x 8 streams: layer problems of order 24)."""
     cfg = Config(do_sw=True, do_lw=False, do_vegetation=True, do_urban=False,
-                 n_vegetation_region_forest=1, n_vegetation_region_urban=1, nsw=1, nlw=1,
-                 n_stream_sw_forest=1, n_stream_sw_urban=2,
+                 n_vegetation_region_forest=n_vegetation_region, n_vegetation_region_urban=1, nsw=1, nlw=1,
+                 n_stream_sw_forest=nstream, n_stream_sw_urban=2,
                  use_symmetric_vegetation_scale_forest=False).consolidate()
     L = 2
     cp = CanopyProperties().set_layers(np.full(ncol, L, dtype=np.int32))
