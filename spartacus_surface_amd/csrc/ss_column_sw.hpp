@@ -368,26 +368,33 @@ struct SwDownIn {
   }
 };
 
-// Staging priority of the per-layer outputs of the downward kernel (see PUTL there)
+// Staging plan of the per-layer outputs of the downward kernel (see PUTL there).  Ten fields x maxlay
+// layers per lane do not fit the 80 LDS slots of a lane at 10 layers, but the two lanes of a column (direct
+// pass on the even lane, diffuse pass on the odd one) do not need the same: the three direct-beam fields are
+// identically zero in the diffuse pass (written as zeros at the end, never staged there).  So the diffuse
+// lane stages the fields of slots 0..6, the direct lane those of slots 0..7 in its own slots and the field
+// of slot 8 in its neighbour's unused slots 7 maxlay .. 8 maxlay - 1; the field of slot 9 is stored as it
+// is computed (direct pass only).
+constexpr int kSwDownFields = 10, kSwDownDiffuseFields = 7, kSwDownOwnFields = 8;
 constexpr int sw_down_slot(int F) {
   switch (F) {
     case F_CLEAR_AIR_ABS: return 0;
     case F_VEG_ABS: return 1;
     case F_VEG_AIR_ABS: return 2;
-    case F_VEG_ABS_DIR: return 3;
-    case F_WALL_IN: return 4;
-    case F_WALL_NET: return 5;
-    case F_ROOF_IN: return 6;
-    case F_ROOF_NET: return 7;
+    case F_WALL_IN: return 3;
+    case F_WALL_NET: return 4;
+    case F_ROOF_IN: return 5;
+    case F_ROOF_NET: return 6;
+    case F_VEG_ABS_DIR: return 7;
     case F_WALL_IN_DIR: return 8;
     case F_ROOF_IN_DIR: return 9;
     default: return -1;
   }
 }
-constexpr int kSwDownSlotField[10] = {F_CLEAR_AIR_ABS, F_VEG_ABS, F_VEG_AIR_ABS, F_VEG_ABS_DIR, F_WALL_IN,
-                                      F_WALL_NET, F_ROOF_IN, F_ROOF_NET, F_WALL_IN_DIR, F_ROOF_IN_DIR};
+constexpr int kSwDownSlotField[kSwDownFields] = {F_CLEAR_AIR_ABS, F_VEG_ABS, F_VEG_AIR_ABS, F_WALL_IN, F_WALL_NET,
+                                                 F_ROOF_IN, F_ROOF_NET, F_VEG_ABS_DIR, F_WALL_IN_DIR, F_ROOF_IN_DIR};
 constexpr bool sw_down_slots_consistent() {
-  for (int s = 0; s < 10; ++s)
+  for (int s = 0; s < kSwDownFields; ++s)
     if (sw_down_slot(kSwDownSlotField[s]) != s) return false;
   return true;
 }
@@ -444,9 +451,15 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
   // The fields that fit are therefore staged in LDS and written out back to back
   // after the sweep, so that every line is completed while it is still in L2.
   LaneLds<(N <= SS_UNROLL_MAX)> obuf;
-  const int nbuf = obuf.kSlots / (L.maxlay > 0 ? L.maxlay : 1);   // fields that fit
+  const int nbuf = obuf.kSlots / (L.maxlay > 0 ? L.maxlay : 1);   // fields that fit a lane's own slots
+  // is the field of slot s_ staged (by the lane that has something to stage)?
+  auto staged = [&](int s_) { return s_ < kSwDownOwnFields ? s_ < nbuf : (s_ == kSwDownOwnFields && nbuf >= kSwDownOwnFields); };
 #define PUTL(F, v) do { double* p_ = FSEL(F); if (p_) { constexpr int s_ = sw_down_slot(F); \
-    if (s_ >= 0 && s_ < nbuf) obuf.put(s_ * L.maxlay + jlay, (v)); else p_[sidx] = (v); } } while (0)
+    if (s_ >= kSwDownDiffuseFields && !dirpass) { /* zero, written after the sweep */ } \
+    else if (s_ >= 0 && staged(s_)) { \
+      if (s_ < kSwDownOwnFields) obuf.put(s_ * L.maxlay + jlay, (v)); \
+      else obuf.put_next(kSwDownDiffuseFields * L.maxlay + jlay, (v)); } \
+    else p_[sidx] = (v); } } while (0)
 
   double dir_above[D], diff_above[N], up_above[N];
   dir_above[0] = dirpass ? 1.0 / cos_sza : 0.0;
@@ -780,11 +793,15 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
   }
   // the staged per-layer fields, all layers of a field back to back
   SS_UNROLL_FULL
-  for (int s_ = 0; s_ < 10; ++s_) {
+  for (int s_ = 0; s_ < kSwDownFields; ++s_) {
     double* p_ = FSEL(kSwDownSlotField[s_]);
-    if (s_ < nbuf && p_) {
-      for (int jlay = 0; jlay < nlay; ++jlay)
-        p_[(long)jb + (long)nspec * (l0 + jlay)] = obuf.get(s_ * L.maxlay + jlay);
+    const bool zero_ = s_ >= kSwDownDiffuseFields && !dirpass;
+    if (p_ && (zero_ || staged(s_))) {
+      for (int jlay = 0; jlay < nlay; ++jlay) {
+        double v_ = 0.0;
+        if (!zero_) v_ = s_ < kSwDownOwnFields ? obuf.get(s_ * L.maxlay + jlay) : obuf.get_next(kSwDownDiffuseFields * L.maxlay + jlay);
+        p_[(long)jb + (long)nspec * (l0 + jlay)] = v_;
+      }
     }
   }
 #undef PUTC

@@ -59,15 +59,24 @@ SS_HD void sw_ground(const LG& lg, double ga, double gad, double cos_sza, const 
 // d_below UNSCALED into the column record; returns a_below^ (packed) and d_below^ (rows scaled).
 // src: the layer record in HBM (RecSource) or what the fused layer stage left in LDS / registers (FusedSource)
 template <int N, int D, class Src>
-SS_HD void sw_adding_step(const Src& src, const double* Aab, const double* Dab, double* crec,
-                          const double* dsc, const double* rd, double* Abe, double* Dbe) {
+SS_HD void sw_adding_step(const Src& src, const Src* next, double* R, double* T, const double* Aab,
+                          const double* Dab, double* crec, const double* dsc, const double* rd, double* Abe,
+                          double* Dbe) {
   using LRec = SwLayRec<N, D>;
   using CRec = SwColRec<N, D>;
   static_assert(LRec::PACKED, "packed layer record");
   constexpr long st = kRecStride;
-  double R[rec_even(kTri<N>)], T[rec_even(kTri<N>)];
-  src.template load<rec_even(kTri<N>)>(LRec::R, R);
-  src.template load<rec_even(kTri<N>)>(LRec::T, T);
+  // Software pipeline of the record loads (every one of them used to be a full memory round trip in the
+  // middle of a layer step: 62 % of the sweep's cycles waited).  R^ and T^ arrive in R, T - requested by the
+  // caller for the first layer, by the previous step for the others.  E and S_dn are requested here, a matrix
+  // factorisation ahead of their use; S_up takes the place of S_dn before the last solve; R^, T^ of the next
+  // layer are requested as soon as T^ has been used for the last time, ahead of the overlap step.  Loads
+  // complete in the order of issue (one counter), so each wait only covers what was requested before it.
+  double E[D * D], S[N * D];
+#if !defined(SS_NO_COLUMN_PREFETCH)
+  src.template load<D * D>(LRec::EDIR, E);
+  src.template load<N * D>(LRec::SDN, S);
+#endif
   SS_LOAD_FENCE(); SS_SCHED_FENCE();
   // denominator = I - a_above^ R^
   double Den[N * N];
@@ -134,9 +143,11 @@ SS_HD void sw_adding_step(const Src& src, const double* Aab, const double* Dab, 
     rec_store<N * N>(crec, st, CRec::ABE, X);
   }
   // d_below^ = S_up^ + T^ Den^-1 (d_above^ E + a_above^ S_dn^);  Q^ = Den^-1 (R^ (d_above^ E) + S_dn^)
-  double E[D * D], S[N * D], Y[N * D];
+  double Y[N * D];
+#if defined(SS_NO_COLUMN_PREFETCH)
   src.template load<D * D>(LRec::EDIR, E);
   src.template load<N * D>(LRec::SDN, S);
+#endif
   mat_mul<N, D, D>(Dab, E, Y);
   {
     double Q[N * D];
@@ -168,8 +179,14 @@ SS_HD void sw_adding_step(const Src& src, const double* Aab, const double* Dab, 
       SS_E(Y, i, j, N) = s;
     }
   }
+#if !defined(SS_NO_COLUMN_PREFETCH)
+  src.template load<N * D>(LRec::SUP, S);
+  SS_LOAD_FENCE(); SS_SCHED_FENCE();
+  lu_solve_mat<N, D>(Den, Y);
+#else
   lu_solve_mat<N, D>(Den, Y);
   src.template load<N * D>(LRec::SUP, S);
+#endif
   SS_UNROLL_FULL
   for (int j = 0; j < D; ++j) {
     SS_UNROLL_FULL
@@ -180,6 +197,14 @@ SS_HD void sw_adding_step(const Src& src, const double* Aab, const double* Dab, 
       SS_E(Dbe, i, j, N) = s;
     }
   }
+#if !defined(SS_NO_COLUMN_PREFETCH)
+  if (next) {
+    SS_SCHED_FENCE();
+    next->template load<rec_even(kTri<N>)>(LRec::R, R);
+    next->template load<rec_even(kTri<N>)>(LRec::T, T);
+    SS_LOAD_FENCE(); SS_SCHED_FENCE();
+  }
+#endif
   SS_UNROLL_FULL
   for (int j = 0; j < D; ++j) {
     SS_UNROLL_FULL
@@ -191,19 +216,34 @@ SS_HD void sw_adding_step(const Src& src, const double* Aab, const double* Dab, 
 // Overlap to the base of the layer above layer jlay, or to the free atmosphere (forest :495-503, urban
 // :627-653), from the scaling of layer jlay (sf_lo, rsf_lo) into that of the layer above (returned in
 // sf_up, rsf_up): a_above^ = U^ [a_below^ V^; roof rows], d_above^ likewise.
+// What the overlap step reads of the input packs (requested at the top of the layer step, see sw_adding_step)
+struct SwOverlapIn {
+  double vf_lo, bf_lo, vf_up, bf_up, roof_albedo, roof_albedo_dir;
+  template <bool URBAN>
+  SS_HD void load(const Launch& L, int cu, int jlay, int nlay) {
+    const double* prec = pack_rec(L, jlay, cu, kPackSw);
+    pack_fractions(prec, vf_lo, bf_lo);
+    vf_up = bf_up = 0.0;
+    if (jlay + 1 < nlay) pack_fractions(pack_rec(L, jlay + 1, cu, kPackSw), vf_up, bf_up);
+    roof_albedo = roof_albedo_dir = 0.0;
+    if (URBAN) {
+      const RecPair ra = rec_pair_load(prec + 8 * kRecStride);   // roof_albedo, roof_albedo_dir
+      roof_albedo = ra.x;
+      roof_albedo_dir = ra.y;
+    }
+  }
+};
+
 template <bool URBAN, int NREG, int NS>
-SS_HD void sw_overlap_above(const Launch& L, int cu, int jlay, int nlay, double cos_sza, const double* Abe,
+SS_HD void sw_overlap_above(const Launch& L, const SwOverlapIn& oi, int jlay, int nlay, double cos_sza, const double* Abe,
                             const double* Dbe, const double* sf_lo, const double* rsf_lo, double* sf_up,
                             double* rsf_up, double* Aab, double* Dab) {
   constexpr int N = NREG * NS, D = NREG;
   constexpr int DB = URBAN ? NREG + 1 : NREG;
   const LG& lg = L.lg;
   double U[NREG * DB], V[DB * NREG];
-  const double* prec = pack_rec(L, jlay, cu, kPackSw);
-  double vf_lo, bf_lo, vf_up = 0.0, bf_up = 0.0;
-  pack_fractions(prec, vf_lo, bf_lo);
+  const double vf_lo = oi.vf_lo, bf_lo = oi.bf_lo, vf_up = oi.vf_up, bf_up = oi.bf_up;
   const bool sky = jlay + 1 >= nlay;
-  if (!sky) pack_fractions(pack_rec(L, jlay + 1, cu, kPackSw), vf_up, bf_up);
   interface_overlap_vals<URBAN, false, NREG>(L.cfg.min_vegetation_fraction, sky, vf_up, bf_up, false, vf_lo, bf_lo, U, V);
   {
     double fu[NREG];
@@ -216,12 +256,7 @@ SS_HD void sw_overlap_above(const Launch& L, int cu, int jlay, int nlay, double 
     }
     region_roots<NREG>(fu, sf_up, rsf_up);
   }
-  double roof_a = 0.0, roof_d = 0.0;
-  if (URBAN) {
-    const RecPair ra = rec_pair_load(prec + 8 * kRecStride);   // roof_albedo, roof_albedo_dir
-    roof_a = ra.x;
-    roof_d = cos_sza * ra.y;
-  }
+  const double roof_a = URBAN ? oi.roof_albedo : 0.0, roof_d = URBAN ? cos_sza * oi.roof_albedo_dir : 0.0;
   // Vs = V^ (diffuse columns: scaled on both sides), Us = U^
   double Vs[DB * NREG], Us[NREG * DB];
   SS_UNROLL_FULL
@@ -317,9 +352,25 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
     region_roots<NREG>(frac, sf, rsf);
   }
   sym::sw_ground<NREG, NS>(L.lg, in.ground_albedo[c.cidx], in.ground_albedo_dir[c.cidx], c.cos_sza, rsf, Aab, Dab);
+  double R[rec_even(kTri<N>)], T[rec_even(kTri<N>)];
+#if !defined(SS_NO_COLUMN_PREFETCH)
+  if (c.nlay > 0) {
+    const RecSource lrec{L.lay + rec_base(0, L.maxlay, LRec::NELEM, cu), kRecStride};
+    lrec.template load<rec_even(kTri<N>)>(LRec::R, R);
+    lrec.template load<rec_even(kTri<N>)>(LRec::T, T);
+  }
+#endif
   for (int jlay = 0; jlay < c.nlay; ++jlay) {
     const RecSource lrec{L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu), kRecStride};
+    const RecSource lnext{L.lay + rec_base(jlay + 1, L.maxlay, LRec::NELEM, cu), kRecStride};
     double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
+    SwOverlapIn oi;
+#if defined(SS_NO_COLUMN_PREFETCH)
+    lrec.template load<rec_even(kTri<N>)>(LRec::R, R);
+    lrec.template load<rec_even(kTri<N>)>(LRec::T, T);
+#else
+    oi.template load<URBAN>(L, cu, jlay, c.nlay);
+#endif
     double dsc[N], rd[N];
     SS_UNROLL_FULL
     for (int r = 0; r < NREG; ++r) {
@@ -330,9 +381,12 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
       }
     }
     double Abe[kTri<N>], Dbe[N * D];
-    sym::sw_adding_step<N, D>(lrec, Aab, Dab, crec, dsc, rd, Abe, Dbe);
+    sym::sw_adding_step<N, D>(lrec, jlay + 1 < c.nlay ? &lnext : nullptr, R, T, Aab, Dab, crec, dsc, rd, Abe, Dbe);
+#if defined(SS_NO_COLUMN_PREFETCH)
+    oi.template load<URBAN>(L, cu, jlay, c.nlay);
+#endif
     double sfu[NREG], rsfu[NREG];
-    sym::sw_overlap_above<URBAN, NREG, NS>(L, cu, jlay, c.nlay, c.cos_sza, Abe, Dbe, sf, rsf, sfu, rsfu, Aab, Dab);
+    sym::sw_overlap_above<URBAN, NREG, NS>(L, oi, jlay, c.nlay, c.cos_sza, Abe, Dbe, sf, rsf, sfu, rsfu, Aab, Dab);
     SS_UNROLL_FULL
     for (int r = 0; r < NREG; ++r) { sf[r] = sfu[r]; rsf[r] = rsfu[r]; }
   }
@@ -381,9 +435,14 @@ SS_HD void layer_up_sw(const Launch& L, int cu) {
     }
     const FusedSource<LRec::EDIR, Lds> src{&lds, hold};
     double Abe[kTri<N>], Dbe[N * D];
-    sym::sw_adding_step<N, D>(src, Aab, Dab, crec, dsc, rd, Abe, Dbe);
+    double R[rec_even(kTri<N>)], T[rec_even(kTri<N>)];
+    src.template load<rec_even(kTri<N>)>(LRec::R, R);
+    src.template load<rec_even(kTri<N>)>(LRec::T, T);
+    sym::sw_adding_step<N, D>(src, (const decltype(src)*)nullptr, R, T, Aab, Dab, crec, dsc, rd, Abe, Dbe);
+    SwOverlapIn oi;
+    oi.template load<URBAN>(L, cu, jlay, c.nlay);
     double sfu[NREG], rsfu[NREG];
-    sym::sw_overlap_above<URBAN, NREG, NS>(L, cu, jlay, c.nlay, c.cos_sza, Abe, Dbe, sf, rsf, sfu, rsfu, Aab, Dab);
+    sym::sw_overlap_above<URBAN, NREG, NS>(L, oi, jlay, c.nlay, c.cos_sza, Abe, Dbe, sf, rsf, sfu, rsfu, Aab, Dab);
     SS_UNROLL_FULL
     for (int r = 0; r < NREG; ++r) { sf[r] = sfu[r]; rsf[r] = rsfu[r]; }
   }

@@ -101,10 +101,16 @@ struct LaneLds {
   }
   SS_HD void put(int slot, double v) const { p[slot * 64] = v; }
   SS_HD double get(int slot) const { return p[slot * 64]; }
+  // the same slot of the NEXT lane (an even lane borrowing what its odd neighbour leaves unused)
+  SS_HD void put_next(int slot, double v) const { p[slot * 64 + 1] = v; }
+  SS_HD double get_next(int slot) const { return p[slot * 64 + 1]; }
 #else
   mutable double a[kLaneLdsSlots] = {};
+  mutable double b[kLaneLdsSlots] = {};
   SS_HD void put(int slot, double v) const { a[slot] = v; }
   SS_HD double get(int slot) const { return a[slot]; }
+  SS_HD void put_next(int slot, double v) const { b[slot] = v; }
+  SS_HD double get_next(int slot) const { return b[slot]; }
 #endif
 };
 // A smaller per-lane scratch of SLOTS doubles, same addressing (the graded-order permutation of the
@@ -133,6 +139,8 @@ struct LaneLds<false> {
   static constexpr int kSlots = 0;
   SS_HD void put(int, double) const {}
   SS_HD double get(int) const { return 0.0; }
+  SS_HD void put_next(int, double) const {}
+  SS_HD double get_next(int) const { return 0.0; }
 };
 
 // doubles per (unit, layer) of the input pack (ss_pack.hpp)
