@@ -189,7 +189,7 @@ int lw_sym_unit(const double* g1, const double* g2, const double* b, const doubl
   using FR = ss::LwRec<N>;
   double tmp[LR::NELEM + 2] = {0.0};
   const ss::ArrayRecWriter w{tmp, nullptr};
-  const ss::LaneLds<true> lds{};
+  const ss::LaneLds<(N <= SS_UNROLL_MAX)> lds{};   // orders above 16: rolled loops, nothing staged (ss_solver_lw.hpp)
   const int rc = ss::sym::calc_matrices_lw_sym<N, N, 0>(g1, g2, b, dsc, dz, w, lds);
   if (LR::PACKED) unpack_rt<N>(tmp, LR::R, LR::T, dsc, rec, FR::R, FR::T);
   else for (int k = 0; k < FR::IFLUX; ++k) rec[k] = tmp[k];
@@ -203,7 +203,7 @@ int sw_sym_unit(const double* g0, const double* g1, const double* g2, const doub
   using FR = ss::SwRec<N, D>;
   double tmp[LR::NELEM + 2] = {0.0};
   const ss::ArrayRecWriter w{tmp, nullptr};
-  const ss::LaneLds<true> lds{};
+  const ss::LaneLds<(N <= SS_UNROLL_MAX)> lds{};
   const int rc = ss::sym::calc_matrices_sw_sym<N, D, N, D, 0, 0>(g0, g1, g2, g3, dsc0, dsc, dz, w, lds);
   if (LR::PACKED) unpack_rt<N>(tmp, LR::R, LR::T, dsc, rec, FR::R, FR::T);
   else for (int k = 0; k < FR::SUP; ++k) rec[k] = tmp[k];
@@ -226,13 +226,14 @@ extern "C" int emul_lw_sym_unit(int n, int nstr, const double* g1, const double*
     case 4: return lw_sym_unit<4>(g1, g2, b, dsc, dz, rec);
     case 5: return lw_sym_unit<5>(g1, g2, b, dsc, dz, rec);
     case 6: return lw_sym_unit<6>(g1, g2, b, dsc, dz, rec);
+    case 24: return lw_sym_unit<24>(g1, g2, b, dsc, dz, rec);
     default: return -99;
   }
 }
 extern "C" int emul_lw_rec_offsets(int n, int* off) {
   switch (n) {
 #define OFFS(N) case N: off[0] = ss::LwRec<N>::R; off[1] = ss::LwRec<N>::T; off[2] = ss::LwRec<N>::IFLUX; off[3] = ss::LwRec<N>::SRC; off[4] = ss::LwRec<N>::ISRC; off[5] = ss::LwRec<N>::NELEM; return 0;
-    OFFS(1) OFFS(2) OFFS(3) OFFS(4) OFFS(5) OFFS(6)
+    OFFS(1) OFFS(2) OFFS(3) OFFS(4) OFFS(5) OFFS(6) OFFS(24)
 #undef OFFS
     default: return -99;
   }
@@ -246,11 +247,12 @@ extern "C" int emul_sw_sym_unit(int n, int d, const double* g0, const double* g1
   if (n == 3 && d == 3) return sw_sym_unit<3, 3>(g0, g1, g2, g3, dsc0, dsc, dz, rec);
   if (n == 2 && d == 1) return sw_sym_unit<2, 1>(g0, g1, g2, g3, dsc0, dsc, dz, rec);
   if (n == 2 && d == 2) return sw_sym_unit<2, 2>(g0, g1, g2, g3, dsc0, dsc, dz, rec);
+  if (n == 24 && d == 3) return sw_sym_unit<24, 3>(g0, g1, g2, g3, dsc0, dsc, dz, rec);
   return -99;
 }
 extern "C" int emul_sw_rec_offsets(int n, int d, int* off) {
 #define OFFS(N, D) if (n == N && d == D) { using R_ = ss::SwRec<N, D>; off[0] = R_::R; off[1] = R_::T; off[2] = R_::SUP; off[3] = R_::SDN; off[4] = R_::EDIR; off[5] = R_::IDIR; off[6] = R_::NELEM; return 0; }
-  OFFS(6, 3) OFFS(4, 2) OFFS(6, 2) OFFS(3, 3) OFFS(2, 1) OFFS(2, 2)
+  OFFS(6, 3) OFFS(4, 2) OFFS(6, 2) OFFS(3, 3) OFFS(2, 1) OFFS(2, 2) OFFS(24, 3)
 #undef OFFS
   return -99;
 }

@@ -22,6 +22,7 @@ CASES = ["simple__test_surfaces", "simple__test_surfaces_1stream", "simple__test
          "simple__test_closed", "single_layer__sp", "single_layer__exp", "single_layer__inf",
          "extra__single_layer-mixed", "extra__ragged-tiles", "urban__1stream", "urban__2stream",
          "urban__4stream", "urban__single", "rami4pilps__vis-med-0.3", "rami4pilps__vis-snw-0.3-2-4",
+         "rami4pilps__vis-snw-0.3-2-8",   # order 24: symmetrised route with rolled loops
          "rami5__HET07_JPS_SUM-56-direct",
          # stream counts beyond the reference's own tests (tests/cases.py: extra_cases)
          "extra__urban-3stream", "extra__urban-5stream", "extra__urban-6stream",

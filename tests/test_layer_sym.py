@@ -66,13 +66,16 @@ def _dist(a, exact):
 
 @pytest.mark.parametrize("nreg,ns,lo,hi,identical", [(3, 2, 1e-2, 1.0, False), (3, 2, 1e-6, 1.0, False),
                                                       (2, 2, 1e-5, 1.0, False), (2, 3, 1e-3, 2.0, True),
-                                                      (3, 1, 1e-4, 1.0, False), (2, 1, 1e-2, 1.0, False)])
+                                                      (3, 1, 1e-4, 1.0, False), (2, 1, 1e-2, 1.0, False),
+                                                      # order 24: the same route with rolled loops (matrices in scratch)
+                                                      (3, 8, 1e-3, 1.0, False)])
 def test_longwave_unit_vs_exact(units, nreg, ns, lo, hi, identical):
     lib, chk = units
     rng = np.random.default_rng(100 * nreg + ns)
-    g0, g1, g2, g3, d0, d1 = _physical_gammas(rng, 40, nreg, ns, ext_lo=lo, ext_hi=hi, identical=identical)
+    nset = 40 if nreg * ns <= 6 else 6
+    g0, g1, g2, g3, d0, d1 = _physical_gammas(rng, nset, nreg, ns, ext_lo=lo, ext_hi=hi, identical=identical)
     n = nreg * ns
-    b = rng.uniform(0.1, 1.0, (40, n)) * np.abs(np.einsum("mii->mi", g1 + g2))
+    b = rng.uniform(0.1, 1.0, (nset, n)) * np.abs(np.einsum("mii->mi", g1 + g2))
     for dz in (0.5, 6.0):
         o = chk.calc_matrices_lw_eig(dz, g1, g2, b, "oracle")
         q = chk.calc_matrices_lw_eig(dz, g1, g2, b, "quad")
@@ -88,11 +91,12 @@ def test_longwave_unit_vs_exact(units, nreg, ns, lo, hi, identical):
             assert e_new <= max(1.0e-9, 2.0 * e_ref), (k, dz, e_new, e_ref)
 
 
-@pytest.mark.parametrize("nreg,ns,lo,hi", [(3, 2, 1e-2, 1.0), (2, 2, 1e-4, 1.0), (2, 3, 1e-3, 1.0), (2, 1, 1e-2, 1.0)])
+@pytest.mark.parametrize("nreg,ns,lo,hi", [(3, 2, 1e-2, 1.0), (2, 2, 1e-4, 1.0), (2, 3, 1e-3, 1.0), (2, 1, 1e-2, 1.0),
+                                           (3, 8, 1e-3, 1.0)])
 def test_shortwave_unit_vs_exact(units, nreg, ns, lo, hi):
     lib, chk = units
     rng = np.random.default_rng(300 + 10 * nreg + ns)
-    g0, g1, g2, g3, d0, d1 = _physical_gammas(rng, 40, nreg, ns, ext_lo=lo, ext_hi=hi)
+    g0, g1, g2, g3, d0, d1 = _physical_gammas(rng, 40 if nreg * ns <= 6 else 6, nreg, ns, ext_lo=lo, ext_hi=hi)
     for dz in (0.5, 6.0):
         # (mu0 only enters the reference's routine through unused arguments: the Gamma matrices carry it)
         o = chk.calc_matrices_sw_eig(dz, 0.6, g0, g1, g2, g3, "oracle")
