@@ -454,12 +454,15 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
   const int nbuf = obuf.kSlots / (L.maxlay > 0 ? L.maxlay : 1);   // fields that fit a lane's own slots
   // is the field of slot s_ staged (by the lane that has something to stage)?
   auto staged = [&](int s_) { return s_ < kSwDownOwnFields ? s_ < nbuf : (s_ == kSwDownOwnFields && nbuf >= kSwDownOwnFields); };
-#define PUTL(F, v) do { double* p_ = FSEL(F); if (p_) { constexpr int s_ = sw_down_slot(F); \
+  // (a staged field is staged whether or not its member is allocated - that is looked at when the fields are
+  // written out: inside the sweep an output pointer is only touched by the fields that are stored directly,
+  // which keeps two dozen wave-uniform pointers out of the scalar registers of the loop)
+#define PUTL(F, v) do { constexpr int s_ = sw_down_slot(F); \
     if (s_ >= kSwDownDiffuseFields && !dirpass) { /* zero, written after the sweep */ } \
     else if (s_ >= 0 && staged(s_)) { \
       if (s_ < kSwDownOwnFields) obuf.put(s_ * L.maxlay + jlay, (v)); \
       else obuf.put_next(kSwDownDiffuseFields * L.maxlay + jlay, (v)); } \
-    else p_[sidx] = (v); } } while (0)
+    else { double* p_ = FSEL(F); if (p_) p_[sidx] = (v); } } while (0)
 
   double dir_above[D], diff_above[N], up_above[N];
   dir_above[0] = dirpass ? 1.0 / cos_sza : 0.0;

@@ -145,7 +145,10 @@ SS_HD int sym_tridiagonal_ql(double* d, double* e, double* z) {
       ++iter;
       // shift
       double g = (d[l + 1 < N ? l + 1 : l] - d[l]) / (2.0 * e[l]);
-      double r = sqrt(g * g + 1.0);
+      // (|g| < 1 / (2 eps) by the test above: g^2 + 1 is far from the ends of the exponent range, and so are
+      // the sums of squares below unless they are exactly zero - the fast square root needs no scaling)
+      double r, rr_;
+      fast_sqrt_rsqrt(g * g + 1.0, r, rr_);
       // d[m] with run-time m
       double dm = 0.0;
       SS_SYM_UNROLL(N)
@@ -158,7 +161,10 @@ SS_HD int sym_tridiagonal_ql(double* d, double* e, double* z) {
         if (i <= m - 1 && !broke) {
           double f = s * e[i];
           const double b = c * e[i];
-          r = sqrt(f * f + g * g);
+          const double h2 = f * f + g * g;
+          double rr;
+          fast_sqrt_rsqrt(h2 > 0.0 ? h2 : 1.0, r, rr);
+          r = h2 > 0.0 ? r : 0.0;
           e[i + 1] = r;
           if (r == 0.0) {
             d[i + 1] -= p;
@@ -167,7 +173,6 @@ SS_HD int sym_tridiagonal_ql(double* d, double* e, double* z) {
             for (int k = l; k < N; ++k) e[k] = (k == m) ? 0.0 : e[k];
             broke = true;
           } else {
-            const double rr = 1.0 / r;
             s = f * rr;
             c = g * rr;
             g = d[i + 1] - p;

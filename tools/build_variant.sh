@@ -8,7 +8,7 @@ OD="${TMPDIR:-/tmp}/ss_variants/$NAME"; mkdir -p $OD ../lib/variants
 # UNITS: the instantiation units rebuilt with the flags (default: the two of the C3 workload)
 UNITS=${UNITS:-"inst_sw_urban_r3 inst_lw_urban_r3"}
 for u in $UNITS; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-cuda-compat -DSS_ONLY_NS=$NSV $FLAGS -c $u.hip -o $OD/$u.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-cuda-compat -fapprox-func -DSS_ONLY_NS=$NSV $FLAGS -c $u.hip -o $OD/$u.o &
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-cuda-compat $FLAGS -c ss_capi.hip -o $OD/ss_capi.o &
 wait
