@@ -190,6 +190,7 @@ class Plan {
   size_t scratch_budget_bytes = 0;
   static constexpr int kDefaultPipes = 4;
   int pipes_wanted = kDefaultPipes;
+  int chunks_per_pipe = 4;
   int pipes_cap = kMaxPipes;     // set before create(): upper limit for this plan
   size_t lay_bytes = 0, col_bytes = 0, eig_bytes = 0;
   // slot 0: eigen failures of the last solve; the rest: section stamps of profiling builds
@@ -362,6 +363,8 @@ class Plan {
     want_profiles = profiles != 0;
     const char* mb = std::getenv("SPARTACUS_SCRATCH_MB");
     scratch_budget_bytes = (mb ? (size_t)std::atol(mb) : (size_t)4096) << 20;
+    const char* cpp = std::getenv("SPARTACUS_CHUNKS_PER_PIPE");
+    chunks_per_pipe = cpp ? std::max(0, std::atoi(cpp)) : 4;
     const char* np = std::getenv("SPARTACUS_PIPES");
     pipes_wanted = std::min(pipes_cap, np ? std::max(1, std::atoi(np)) : kDefaultPipes);
     be.init();
@@ -617,10 +620,25 @@ class Plan {
 
   // Columns of class c solved per launch so that both scratch buffers stay
   // within the budget
+  // ... and so that a class gives every pipe several chunks (chunks_per_pipe, default 4, env
+  // SPARTACUS_CHUNKS_PER_PIPE; 0: the budget alone decides): the layer kernels are compute-bound and the sweep
+  // kernels bandwidth-bound, and the pipes only overlap the two kinds when they are in different phases -
+  // with one chunk per pipe all of them run their layer kernel together and then their sweeps together
+  // (C3, 10^6 columns: 62.9 -> 68.5e6 columns/s from 1 to 4 chunks per pipe and family).  Not below
+  // kMinChunkUnits column-units, which still fill the device twice over.
+  static constexpr size_t kMinChunkUnits = 16384;
   size_t chunk_columns(const ColumnClass& c, bool lw, int nspec) const {
     const size_t per_col = (size_t)nspec * c.maxlay * sizeof(double)
                            * (lay_nelem(lw, c.key) + col_nelem(lw, c.key) + eig_nelem(c.key));
     size_t chunk = std::max<size_t>(1, scratch_budget_bytes / std::max<size_t>(1, per_col));
+    if (chunks_per_pipe > 0) {
+      // (counted for the default number of pipes, so that the chunk size - and with it the size of the
+      // scratch buffers - does not depend on set_pipes())
+      const size_t parts = (size_t)chunks_per_pipe * (size_t)kDefaultPipes;
+      const size_t floor_cols = (kMinChunkUnits + (size_t)nspec - 1) / (size_t)std::max(1, nspec);
+      const size_t even = std::max(floor_cols, (c.cols.size() + parts - 1) / parts);
+      chunk = std::min(chunk, (even + 63) / 64 * 64);
+    }
     if (chunk >= 128) chunk -= chunk % 64;     // whole waves where possible
     return std::max<size_t>(1, std::min(chunk, c.cols.size()));
   }
@@ -820,29 +838,48 @@ class Plan {
       }
       be.fork(npipes);
       forked = true;
-      int nlaunched = 0;
+      // the chunks of the two spectral regions, launched alternately (a pipe then mostly stays with one
+      // region, and the regions' kernels have different lengths: the pipes drift out of phase)
+      struct Item { int lw; const ColumnClass* c; size_t first, count; };
+      std::vector<Item> items[2];
       for (int lw = 0; lw < 2; ++lw) {
         const auto& classes = lw ? lw_classes : sw_classes;
         const int nspec = lw ? nlw : nsw;
         for (const auto& c : classes) {
           const size_t chunk = chunk_columns(c, lw != 0, nspec);
-          for (size_t first = 0; first < c.cols.size(); first += chunk) {
-            const size_t count = std::min(chunk, c.cols.size() - first);
-            const int chunk_maxlay = h_nlay[c.cols[first]];   // sorted descending
-            // Orders above SS_UNROLL_MAX that the row-of-16 kernels do not take (above 16) keep
-            // their matrices in the hardware scratch (tens of KB per lane, GBs per queue):
-            // concurrent queues then fight over it (measured 5.5e5 -> 3.2e5 columns/s with four
-            // streams at n = 12 in the one-lane form), so those classes stay on the first stream.
-            // (The cooperative orders, 7..16, keep their one-lane second pass - 17 KB of scratch per lane
-            // for the units the cooperative route declines - on the first stream whatever their pipe:
-            // launch_ns, "fallback".)
-            const int order = c.key.nreg * c.key.ns;
-            const bool big_order = order > SS_UNROLL_MAX && !coop_order(order);
-            const int pipe = big_order ? 0 : nlaunched++ % npipes;
-            Launch L = make_launch(c, lw != 0, first, count, chunk_maxlay, pipe);
-            be.launch_solver(c.key, lw != 0, L, timers, pipe);
-          }
+          for (size_t first = 0; first < c.cols.size(); first += chunk)
+            items[lw].push_back(Item{lw, &c, first, std::min(chunk, c.cols.size() - first)});
         }
+      }
+      std::vector<Item> sequence;
+      for (size_t k = 0; k < std::max(items[0].size(), items[1].size()); ++k)
+        for (int lw = 0; lw < 2; ++lw)
+          if (k < items[lw].size()) sequence.push_back(items[lw][k]);
+      // every chunk goes to the pipe with the least work so far (a shortwave chunk costs about 4/3 of a
+      // longwave chunk of the same size: 9.7 against 7.5 ms per 10^6 columns of C3)
+      double pipe_load[kMaxPipes] = {0.0};
+      for (const Item& it : sequence) {
+        const int lw = it.lw;
+        const ColumnClass& c = *it.c;
+        const size_t first = it.first, count = it.count;
+        const int chunk_maxlay = h_nlay[c.cols[first]];   // sorted descending
+        // Orders above SS_UNROLL_MAX that the row-of-16 kernels do not take (above 16) keep
+        // their matrices in the hardware scratch (tens of KB per lane, GBs per queue):
+        // concurrent queues then fight over it (measured 5.5e5 -> 3.2e5 columns/s with four
+        // streams at n = 12 in the one-lane form), so those classes stay on the first stream.
+        // (The cooperative orders, 7..16, keep their one-lane second pass - 17 KB of scratch per lane
+        // for the units the cooperative route declines - on the first stream whatever their pipe:
+        // launch_ns, "fallback".)
+        const int order = c.key.nreg * c.key.ns;
+        const bool big_order = order > SS_UNROLL_MAX && !coop_order(order);
+        int pipe = 0;
+        if (!big_order) {
+          for (int q = 1; q < npipes; ++q)
+            if (pipe_load[q] < pipe_load[pipe]) pipe = q;
+          pipe_load[pipe] += (double)count * (lw ? nlw : nsw) * chunk_maxlay * (lw ? 3.0 : 4.0);
+        }
+        Launch L = make_launch(c, lw != 0, first, count, chunk_maxlay, pipe);
+        be.launch_solver(c.key, lw != 0, L, timers, pipe);
       }
       be.join(npipes);
       forked = false;
