@@ -254,7 +254,7 @@ struct LwFusedWriter {
 // Layer matrices and adding step of every layer of a column unit on one lane (k_layer_up, see
 // the header of the fused kernels in ss_layer_matrices.hpp)
 template <bool URBAN, int NREG, int NS>
-SS_HD void layer_up_lw(const Launch& L, int cu) {
+SS_HD void layer_up_lw_full(const Launch& L, int cu) {
   constexpr int N = NREG * NS;
   using LRec = LwRec<N>;
   using CRec = LwColRec<N>;

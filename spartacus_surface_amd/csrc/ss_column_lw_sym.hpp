@@ -37,17 +37,17 @@ SS_HD void lw_ground(const LG& lg, double gem, double gemission, const double* s
 
 // One layer: consumes R^, T^ (packed) and source_lay (unscaled) of the layer record; stores P, RSD, source_below
 // unscaled and a_below^ packed into the column record; returns a_below^ and source_below^ (scaled).
-template <int N>
-SS_HD void lw_up_step(const double* lrec, const double* Aab, const double* Sab, double* crec, const double* dsc,
+template <int N, class Src>
+SS_HD void lw_up_step(const Src& lrec, const double* Aab, const double* Sab, double* crec, const double* dsc,
                       const double* rd, double* Abe, double* Sbe) {
   using LRec = LwLayRec<N>;
   using CRec = LwColRec<N>;
   static_assert(LRec::PACKED && CRec::PACKED, "packed records");
   constexpr long st = kRecStride;
   double R[rec_even(kTri<N>)], T[rec_even(kTri<N>)], Sl[N];
-  rec_load<rec_even(kTri<N>)>(lrec, st, LRec::R, R);
-  rec_load<rec_even(kTri<N>)>(lrec, st, LRec::T, T);
-  rec_load<N>(lrec, st, LRec::SRC, Sl);
+  lrec.template load<rec_even(kTri<N>)>(LRec::R, R);
+  lrec.template load<rec_even(kTri<N>)>(LRec::T, T);
+  lrec.template load<N>(LRec::SRC, Sl);
   SS_LOAD_FENCE(); SS_SCHED_FENCE();
   SS_UNROLL_FULL
   for (int i = 0; i < N; ++i) Sl[i] *= rd[i];
@@ -249,7 +249,7 @@ SS_HD void column_up_lw(const Launch& L, int cu) {
   }
   sym::lw_ground<NREG, NS>(L.lg, in.ground_emissivity[cidx], in.ground_emission[cidx], sf, Aab, Sab);
   for (int jlay = 0; jlay < nlay; ++jlay) {
-    const double* lrec = L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu);
+    const RecSource lrec{L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu), kRecStride};
     double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
     double dsc[N], rd[N];
     SS_UNROLL_FULL
@@ -270,7 +270,132 @@ SS_HD void column_up_lw(const Launch& L, int cu) {
   sym::lw_top<NREG, NS>(L, cidx, Aab, Sab);
 }
 
+// ---- layer matrices AND adding step of every layer of a column unit on one lane (k_layer_up), both in the
+// scaled coordinates (-DSS_SYM_FUSE_LW) ----
+// The layer unit writes R^, T^ (2 x 22 slots) and the layer's source (6) into the lane's LDS slots; the
+// integrated-flux matrix and source, which only the downward sweep reads, go straight to the column record.
+// No layer record exists.  Nothing is carried across the layer stage: a_above^ / source_above^ of a layer are
+// formed from a_below^ / source_below of the layer below, which the previous step wrote to the column record
+// for the downward sweep anyway (cache), and the scaling of either layer follows from its two fractions.
+template <int N, class Lds>
+struct LwSymFusedWriter {
+  using LRec = LwLayRec<N>;
+  using CRec = LwColRec<N>;
+  static constexpr int kSrcSlot = LRec::IFLUX;      // the source follows R^, T^ in the slots
+  const Lds* lds;
+  double* crec;
+  long stride;
+  unsigned long long* stamps;
+  SS_HD void put2(int e, double v0, double v1) const {
+    if (e < LRec::IFLUX) {
+      lds->put(e, v0);
+      lds->put(e + 1, v1);
+    } else if (e < LRec::SRC) {
+      rec_pair_store(crec + (long)(CRec::IFLUX + e - LRec::IFLUX) * stride, v0, v1);
+    } else if (e < LRec::ISRC) {
+      lds->put(kSrcSlot + e - LRec::SRC, v0);
+      lds->put(kSrcSlot + e + 1 - LRec::SRC, v1);
+    } else {
+      rec_pair_store(crec + (long)(CRec::ISRC + e - LRec::ISRC) * stride, v0, v1);
+    }
+  }
+  SS_HD const Lds& scratch() const { return *lds; }   // the slots are free until R^ and T^ are put
+};
+template <int N, class Lds>
+struct LwSymFusedSource {
+  using LRec = LwLayRec<N>;
+  const Lds* lds;
+  template <int NEL>
+  SS_HD void load(int off, double* dst) const {
+    const int at = (off < LRec::IFLUX) ? off : LwSymFusedWriter<N, Lds>::kSrcSlot + off - LRec::SRC;
+    SS_UNROLL_FULL
+    for (int k = 0; k < NEL; ++k) dst[k] = lds->get(at + k);
+  }
+};
+
+// square roots of the region fractions of layer jlay (and their reciprocals)
+template <bool URBAN, int NREG>
+SS_HD void lw_layer_roots(const Launch& L, int cu, int jlay, double* sf, double* rsf) {
+  double vf, bf, frac[NREG];
+  pack_fractions(pack_rec(L, jlay, cu, kPackLw), vf, bf);
+  region_fractions<URBAN, true, NREG>(vf, bf, frac);
+  region_roots<NREG>(frac, sf, rsf);
+}
+
+template <bool URBAN, int NREG, int NS>
+SS_HD void layer_up_lw(const Launch& L, int cu) {
+  constexpr int N = NREG * NS;
+  using LRec = LwLayRec<N>;
+  using CRec = LwColRec<N>;
+  static_assert(CRec::FUSED && LRec::PACKED && CRec::PACKED && LRec::IFLUX + N <= kLaneLdsSlots,
+                "R^, T^ and the source must fit the lane's LDS slots");
+  using Lds = LaneLds<true>;
+  constexpr long st = kRecStride;
+  const Inputs& in = L.in;
+  const int col = L.cols[cu / L.nspec];
+  const int jb = cu % L.nspec;
+  const int nlay = in.nlay[col];
+  const long cidx = (long)jb + (long)L.nspec * col;
+  const Lds lds{};
+  // a_above^ / source_above^ at the top of layer jlo, in the scaling of the layer above it (or of the sky),
+  // from the column record of layer jlo
+  auto above = [&](int jlo, double* sf_up, double* rsf_up, double* Aab, double* Sab) {
+    const double* prev = L.col + rec_base(jlo, L.maxlay, CRec::NELEM, cu);
+    double Abe[rec_even(kTri<N>)], Sbe[N];
+    rec_load<rec_even(kTri<N>)>(prev, st, CRec::ABE, Abe);
+    rec_load<N>(prev, st, CRec::SBE, Sbe);
+    double sfl[NREG], rsfl[NREG];
+    lw_layer_roots<URBAN, NREG>(L, cu, jlo, sfl, rsfl);
+    SS_UNROLL_FULL
+    for (int r = 0; r < NREG; ++r) {
+      SS_UNROLL_FULL
+      for (int s = 0; s < NS; ++s) Sbe[s + r * NS] *= rsfl[r] * L.lg.rsqrt_wmu[s];   // stored unscaled
+    }
+    sym::lw_overlap_above<URBAN, NREG, NS>(L, cu, jlo, nlay, Abe, Sbe, sfl, rsfl, sf_up, rsf_up, Aab, Sab);
+  };
+  double Aab[kTri<N>], Sab[N], sf[NREG], rsf[NREG];
+  for (int jlay = 0; jlay < nlay; ++jlay) {
+    double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
+    const LwSymFusedWriter<N, Lds> w{&lds, crec, st, (unsigned long long*)L.eigen_fail};
+    layer_unit_lw<URBAN, NREG, NS>(L, cu, jlay, w);
+    if (jlay == 0) {
+      lw_layer_roots<URBAN, NREG>(L, cu, 0, sf, rsf);
+      sym::lw_ground<NREG, NS>(L.lg, in.ground_emissivity[cidx], in.ground_emission[cidx], sf, Aab, Sab);
+    } else {
+      above(jlay - 1, sf, rsf, Aab, Sab);
+    }
+    double dsc[N], rd[N];
+    SS_UNROLL_FULL
+    for (int r = 0; r < NREG; ++r) {
+      SS_UNROLL_FULL
+      for (int s = 0; s < NS; ++s) {
+        dsc[s + r * NS] = sf[r] * L.lg.sqrt_wmu[s];
+        rd[s + r * NS] = rsf[r] * L.lg.rsqrt_wmu[s];
+      }
+    }
+    const LwSymFusedSource<N, Lds> src{&lds};
+    double Abe[kTri<N>], Sbe[N];
+    sym::lw_up_step<N>(src, Aab, Sab, crec, dsc, rd, Abe, Sbe);
+  }
+  if (nlay > 0) {
+    above(nlay - 1, sf, rsf, Aab, Sab);
+  } else {
+    double frac[NREG];
+    region_fractions<URBAN, true, NREG>(0.0, 0.0, frac);
+    region_roots<NREG>(frac, sf, rsf);
+    sym::lw_ground<NREG, NS>(L.lg, in.ground_emissivity[cidx], in.ground_emission[cidx], sf, Aab, Sab);
+  }
+  sym::lw_top<NREG, NS>(L, cidx, Aab, Sab);
+}
+
 }  // namespace sym
+
+// layer + upward sweep on one lane (k_layer_up)
+template <bool URBAN, int NREG, int NS>
+SS_HD void layer_up_lw(const Launch& L, int cu) {
+  if constexpr (LwLayRec<NREG * NS>::PACKED && LwColRec<NREG * NS>::PACKED) sym::layer_up_lw<URBAN, NREG, NS>(L, cu);
+  else layer_up_lw_full<URBAN, NREG, NS>(L, cu);
+}
 
 // The upward sweep of one column unit (k_column): in symmetrised coordinates where the records are packed
 template <bool URBAN, int NREG, int NS>

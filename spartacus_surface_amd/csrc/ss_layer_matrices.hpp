@@ -264,6 +264,10 @@ constexpr bool fused_order(int n, bool lw) {
   return n <= SS_UNROLL_MAX || (false && lw);
 #elif defined(SS_FUSE_LW)
   return lw && n <= SS_UNROLL_MAX && n < SS_COOP_MIN_ORDER;
+#elif defined(SS_SYM_FUSE_LW)
+  // layer + upward sweep of the longwave on one lane, both in symmetrised coordinates (ss_column_lw_sym.hpp:
+  // sym::layer_up_lw): R^, T^ and the layer's source wait in LDS slots, no layer record exists
+  return lw && n >= 3 && n <= SS_UNROLL_MAX;
 #elif defined(SS_SYM_FUSE_SW)
   // layer + upward sweep of the shortwave on one lane, both in symmetrised coordinates (ss_column_sw_sym.hpp:
   // sym::layer_up_sw): R^, T^, S_up^, S_dn^ wait in the 80 LDS slots of the lane, no layer record exists
