@@ -73,14 +73,40 @@ SS_HD void column_up_lw(const Launch& L, int cu) {
     for (int j = 0; j < N; ++j) Aab[j] = select(g.rg[j / NS], (1.0 - gem) * g.hw, rv(0.0));
     Sab = (g.hw * fr) * gemission;
   }
+  // Software pipeline of the record loads (see sym::sw_adding_step, ss_column_sw_sym.hpp): R, T and the source of
+  // a layer are requested by the previous step - after its last use of T, ahead of its overlap stage -, the
+  // fractions and roof properties of the overlap stage at the top of the step.  Loads complete in the order
+  // of issue, so every wait only covers what was requested before it.  Measured (C3 with 4 streams, ms per
+  // step on one stream): shortwave sweep 5.16 -> 3.83, longwave sweep 3.33 -> 3.47 - the longwave step has a
+  // single load point and two waves per SIMD cover it; so the shortwave sweep is pipelined
+  // (-DSS_NO_COLUMN16_PREFETCH: off) and the longwave sweep is not (-DSS_COLUMN16_PREFETCH_LW: on).
+  rv R[N], T[N], Sl, Rn[N], Sn;
+#if defined(SS_COLUMN16_PREFETCH_LW)
+  if (nlay > 0) {
+    const double* lrec = L.lay + rec_base(0, L.maxlay, LRec::NELEM, cu);
+    load_colmajor<N, N>(lrec, st, LRec::R, R);
+    load_colmajor<N, N>(lrec, st, LRec::T, T);
+    Sl = load_vec<N>(lrec, st, LRec::SRC);
+  }
+#endif
   for (int jlay = 0; jlay < nlay; ++jlay) {
     const double* lrec = L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu);
     double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
     // (R turns into a_below in place and T into P: five matrices live at the peak)
-    rv R[N], T[N], Sbe;
+    rv Sbe;
+    const double* prec = pack_rec(L, jlay, cu, kPackLw);
+    double vf_lo, bf_lo, vf_up = 0.0, bf_up = 0.0;
+    RecPair re{0.0, 0.0};
+#if !defined(SS_COLUMN16_PREFETCH_LW)
     load_colmajor<N, N>(lrec, st, LRec::R, R);
     load_colmajor<N, N>(lrec, st, LRec::T, T);
-    const rv Sl = load_vec<N>(lrec, st, LRec::SRC);
+    Sl = load_vec<N>(lrec, st, LRec::SRC);
+#else
+    pack_fractions(prec, vf_lo, bf_lo);
+    if (jlay + 1 < nlay) pack_fractions(pack_rec(L, jlay + 1, cu, kPackLw), vf_up, bf_up);
+    if (URBAN) re = rec_pair_load(prec + 14 * kRecStride);   // roof_emissivity, roof_emission
+    SS_LOAD_FENCE(); SS_SCHED_FENCE();
+#endif
     {
       // denominator = I - a_above R
       LU<N> Den;
@@ -113,20 +139,30 @@ SS_HD void column_up_lw(const Launch& L, int cu) {
       store_colmajor<N, N>(crec, st, CRec::PDN, T);
     }
     const rv* Abe = R;
+#if defined(SS_COLUMN16_PREFETCH_LW)
+    if (jlay + 1 < nlay) {
+      const double* lnext = L.lay + rec_base(jlay + 1, L.maxlay, LRec::NELEM, cu);
+      SS_SCHED_FENCE();
+      load_colmajor<N, N>(lnext, st, LRec::R, Rn);
+      load_colmajor<N, N>(lnext, st, LRec::T, T);
+      Sn = load_vec<N>(lnext, st, LRec::SRC);
+      SS_LOAD_FENCE(); SS_SCHED_FENCE();
+    }
+#endif
     // overlap to the base of the layer above, or to the free atmosphere (forest :495-506, urban :583-626)
     {
       double U[NREG * DB], V[DB * NREG];
-      const double* prec = pack_rec(L, jlay, cu, kPackLw);
-      double vf_lo, bf_lo, vf_up = 0.0, bf_up = 0.0;
+#if !defined(SS_COLUMN16_PREFETCH_LW)
       pack_fractions(prec, vf_lo, bf_lo);
       if (jlay + 1 < nlay) pack_fractions(pack_rec(L, jlay + 1, cu, kPackLw), vf_up, bf_up);
+      if (URBAN) re = rec_pair_load(prec + 14 * kRecStride);   // roof_emissivity, roof_emission
+#endif
       interface_overlap_vals<URBAN, true, NREG>(L.cfg.min_vegetation_fraction, jlay + 1 >= nlay, vf_up, bf_up,
                                                 false, vf_lo, bf_lo, U, V);
       double roof_a = 0.0, roof_emis = 0.0, exposed_roof_frac = 0.0;
       if (URBAN) {
         if (jlay < nlay - 1) exposed_roof_frac = ss_max(0.0, bf_lo - bf_up);
         else exposed_roof_frac = bf_lo;
-        const RecPair re = rec_pair_load(prec + 14 * kRecStride);   // roof_emissivity, roof_emission
         roof_a = 1.0 - re.x;
         roof_emis = re.y;
       }
@@ -143,6 +179,11 @@ SS_HD void column_up_lw(const Launch& L, int cu) {
         Sab = Sab + ur * (roof_emis * exposed_roof_frac);
       }
     }
+#if defined(SS_COLUMN16_PREFETCH_LW)
+    SS_UNROLL_FULL
+    for (int j = 0; j < N; ++j) R[j] = Rn[j];
+    Sl = Sn;
+#endif
   }
   // top-of-canopy emissivity and emission (lw_top)
   {
@@ -179,13 +220,39 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
     SS_UNROLL_FULL
     for (int r = 0; r < D; ++r) Dab[r] = select(g.rg[r], (c.cos_sza * gad) * g.hw, rv(0.0));
   }
+  // (software pipeline of the record loads: see column_up_lw above; the small direct-beam blocks E, S_dn, S_up
+  // of a layer are requested at the top of its step, a factorisation ahead of their use)
+  rv R[N], T[N], Rn[N];
+#if !defined(SS_NO_COLUMN16_PREFETCH)
+  if (c.nlay > 0) {
+    const double* lrec = L.lay + rec_base(0, L.maxlay, LRec::NELEM, cu);
+    load_colmajor<N, N>(lrec, st, LRec::R, R);
+    load_colmajor<N, N>(lrec, st, LRec::T, T);
+  }
+#endif
   for (int jlay = 0; jlay < c.nlay; ++jlay) {
     const double* lrec = L.lay + rec_base(jlay, L.maxlay, LRec::NELEM, cu);
     double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
     // (R turns into a_below in place and T into P: five matrices live at the peak)
-    rv R[N], T[N], Dbe[D];
+    rv Dbe[D];
+    const double* prec = pack_rec(L, jlay, cu, kPackSw);
+    double vf_lo, bf_lo, vf_up = 0.0, bf_up = 0.0;
+    RecPair ra{0.0, 0.0};
+    double E[D * D];
+    rv S[D];
+#if defined(SS_NO_COLUMN16_PREFETCH)
     load_colmajor<N, N>(lrec, st, LRec::R, R);
     load_colmajor<N, N>(lrec, st, LRec::T, T);
+#else
+    SS_UNROLL_FULL
+    for (int k = 0; k < D * D; ++k) E[k] = rec_elem_load(lrec, st, LRec::EDIR + k);
+    load_colmajor<N, D>(lrec, st, LRec::SDN, S);
+    load_colmajor<N, D>(lrec, st, LRec::SUP, Dbe);
+    pack_fractions(prec, vf_lo, bf_lo);
+    if (jlay + 1 < c.nlay) pack_fractions(pack_rec(L, jlay + 1, cu, kPackSw), vf_up, bf_up);
+    if (URBAN) ra = rec_pair_load(prec + 8 * kRecStride);   // roof_albedo, roof_albedo_dir
+    SS_LOAD_FENCE(); SS_SCHED_FENCE();
+#endif
     {
       // denominator = I - a_above R
       LU<N> Den;
@@ -196,11 +263,12 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
       rv Y[D];
       {
         // Q = Den^-1 (R (d_above E) + S_dn);  Y = Den^-1 (d_above E + a_above S_dn)
-        double E[D * D];
+        rv Q[D];
+#if defined(SS_NO_COLUMN16_PREFETCH)
         SS_UNROLL_FULL
         for (int k = 0; k < D * D; ++k) E[k] = rec_elem_load(lrec, st, LRec::EDIR + k);
-        rv S[D], Q[D];
         load_colmajor<N, D>(lrec, st, LRec::SDN, S);
+#endif
         SS_UNROLL_FULL
         for (int j = 0; j < D; ++j) {
           rv acc = 0.0;
@@ -224,7 +292,9 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
         store_colmajor<N, N>(crec, st, CRec::ABE, R);
       }
       // d_below = S_up + T Y
+#if defined(SS_NO_COLUMN16_PREFETCH)
       load_colmajor<N, D>(lrec, st, LRec::SUP, Dbe);
+#endif
       mul<N, D, true, false>(T, nullptr, Y, Dbe);
       store_colmajor<N, D>(crec, st, CRec::DBE, Dbe);
       // P = Den^-1 T
@@ -232,18 +302,27 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
       store_colmajor<N, N>(crec, st, CRec::PDN, T);
     }
     const rv* Abe = R;
+#if !defined(SS_NO_COLUMN16_PREFETCH)
+    if (jlay + 1 < c.nlay) {
+      const double* lnext = L.lay + rec_base(jlay + 1, L.maxlay, LRec::NELEM, cu);
+      SS_SCHED_FENCE();
+      load_colmajor<N, N>(lnext, st, LRec::R, Rn);
+      load_colmajor<N, N>(lnext, st, LRec::T, T);
+      SS_LOAD_FENCE(); SS_SCHED_FENCE();
+    }
+#endif
     // overlap to the base of the layer above, or to the free atmosphere (forest :495-503, urban :627-653)
     {
       double U[NREG * DB], V[DB * NREG];
-      const double* prec = pack_rec(L, jlay, cu, kPackSw);
-      double vf_lo, bf_lo, vf_up = 0.0, bf_up = 0.0;
+#if defined(SS_NO_COLUMN16_PREFETCH)
       pack_fractions(prec, vf_lo, bf_lo);
       if (jlay + 1 < c.nlay) pack_fractions(pack_rec(L, jlay + 1, cu, kPackSw), vf_up, bf_up);
+      if (URBAN) ra = rec_pair_load(prec + 8 * kRecStride);   // roof_albedo, roof_albedo_dir
+#endif
       interface_overlap_vals<URBAN, false, NREG>(L.cfg.min_vegetation_fraction, jlay + 1 >= c.nlay, vf_up, bf_up,
                                                  false, vf_lo, bf_lo, U, V);
       double roof_a = 0.0, roof_d = 0.0;
       if (URBAN) {
-        const RecPair ra = rec_pair_load(prec + 8 * kRecStride);   // roof_albedo, roof_albedo_dir
         roof_a = ra.x;
         roof_d = c.cos_sza * ra.y;
       }
@@ -268,6 +347,10 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
         for (int ju = 0; ju < D; ++ju) Dab[ju] = Dab[ju] + ur * (roof_d * SS_E(V, DB - 1, ju, DB));
       }
     }
+#if !defined(SS_NO_COLUMN16_PREFETCH)
+    SS_UNROLL_FULL
+    for (int j = 0; j < N; ++j) R[j] = Rn[j];
+#endif
   }
   // top-of-canopy albedos (forest :520-528, urban :666-674)
   {

@@ -477,12 +477,22 @@ SS_HD void column_down_sw(const Launch& L, int cu) {
     // direct beam through the layer, and its contribution to the diffuse flux at the base
     double dir_conv[D];
     rv t3;
+    // (-DSS_DOWN16_PIPE requests the record loads of a stage one stage ahead: P before the direct-beam stage,
+    // a_below / d_below of the layer below before the product with P, int_dir before the interface.  Measured
+    // and OFF: the kernel is at its 256 registers, 22 -> 53 spilled dwords, 4.34 -> 5.55 ms per step of C3 with
+    // 4 streams.)
+    rv P[N];
     {
       double E[D * D];
       SS_UNROLL_FULL
       for (int k = 0; k < D * D; ++k) E[k] = rec_elem_load(lrec, st, LRec::EDIR + k);
       rv Q[D];
       load_colmajor<N, D>(crec, st, CRec::QDN, Q);
+#if defined(SS_DOWN16_PIPE)
+      SS_LOAD_FENCE(); SS_SCHED_FENCE();
+      load_colmajor<N, N>(crec, st, CRec::PDN, P);
+      SS_LOAD_FENCE(); SS_SCHED_FENCE();
+#endif
       t3 = 0.0;
       SS_UNROLL_FULL
       for (int r = 0; r < D; ++r) t3 = t3 + Q[r] * dir_below[r];
@@ -504,24 +514,47 @@ SS_HD void column_down_sw(const Launch& L, int cu) {
       all_sum2<N>(ubc, s_top_up);
     }
     // flux at the base of the layer: diff = P diff_top + Q dir_top
-    {
-      rv P[N];
-      load_colmajor<N, N>(crec, st, CRec::PDN, P);
-      diff_above[0] = t3;
-      diff_above[1] = 0.0;
-      mat_vec2<N, true>(P, dbc, diff_above);
-    }
+    rv ABE[N], DBE[D];
+    double lo[4] = {0.0, 0.0, 0.0, 0.0};
+    double IDIR[D * D];
+#if defined(SS_DOWN16_PIPE)
     if (jlay > 0) {
       const double* crec_n = L.col + rec_base(jlay - 1, L.maxlay, CRec::NELEM, cu);
       const double* pn = pack_rec(L, jlay - 1, cu, kPackSw);
-      double lo[4];
       pack_fractions(pn, lo[0], lo[1]);
       const RecPair ra = rec_pair_load(pn + 8 * kRecStride);   // roof_albedo, roof_albedo_dir
       lo[2] = ra.x;
       lo[3] = ra.y;
-      rv ABE[N], DBE[D];
       load_colmajor<N, N>(crec_n, st, CRec::ABE, ABE);
       load_colmajor<N, D>(crec_n, st, CRec::DBE, DBE);
+    }
+    SS_LOAD_FENCE(); SS_SCHED_FENCE();
+#endif
+    {
+#if !defined(SS_DOWN16_PIPE)
+      load_colmajor<N, N>(crec, st, CRec::PDN, P);
+#endif
+      diff_above[0] = t3;
+      diff_above[1] = 0.0;
+      mat_vec2<N, true>(P, dbc, diff_above);
+    }
+#if defined(SS_DOWN16_PIPE)
+    SS_SCHED_FENCE();
+    SS_UNROLL_FULL
+    for (int k = 0; k < D * D; ++k) IDIR[k] = rec_elem_load(lrec, st, LRec::IDIR + k);
+    SS_LOAD_FENCE(); SS_SCHED_FENCE();
+#endif
+    if (jlay > 0) {
+#if !defined(SS_DOWN16_PIPE)
+      const double* crec_n = L.col + rec_base(jlay - 1, L.maxlay, CRec::NELEM, cu);
+      const double* pn = pack_rec(L, jlay - 1, cu, kPackSw);
+      pack_fractions(pn, lo[0], lo[1]);
+      const RecPair ra = rec_pair_load(pn + 8 * kRecStride);   // roof_albedo, roof_albedo_dir
+      lo[2] = ra.x;
+      lo[3] = ra.y;
+      load_colmajor<N, N>(crec_n, st, CRec::ABE, ABE);
+      load_colmajor<N, D>(crec_n, st, CRec::DBE, DBE);
+#endif
       cross(lo, false, geo.veg_fraction, geo.building_fraction, ABE, DBE, up_above);
     } else {
       // the ground (forest :479-484, urban :612-617): Lambertian, per region
@@ -556,9 +589,10 @@ SS_HD void column_down_sw(const Launch& L, int cu) {
     }
     double int_flux_dir[D];
     {
-      double IDIR[D * D];
+#if !defined(SS_DOWN16_PIPE)
       SS_UNROLL_FULL
       for (int k = 0; k < D * D; ++k) IDIR[k] = rec_elem_load(lrec, st, LRec::IDIR + k);
+#endif
       SS_UNROLL_FULL
       for (int r = 0; r < D; ++r) {
         double t = 0.0;

@@ -2,7 +2,7 @@
 # usage: spillcheck.sh [extra flags]  -> register/scratch metadata of the C3 kernels (urban, 3 regions, 2 streams)
 mkdir -p /tmp/spillcheck; cd "$(dirname "$0")/../spartacus_surface_amd/csrc"
 for f in inst_sw_urban_r3 inst_lw_urban_r3; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fapprox-func -I../../include -DSS_ONLY_NS=2 "$@" --cuda-device-only -S $f.hip -o /tmp/spillcheck/$f.s 2>/dev/null &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fapprox-func -I../../include -DSS_ONLY_NS=${NSV:-2} "$@" --cuda-device-only -S $f.hip -o /tmp/spillcheck/$f.s 2>/dev/null &
 done
 wait
 for f in inst_sw_urban_r3 inst_lw_urban_r3; do
