@@ -173,7 +173,7 @@ struct Cfg {
   // diagnostic (env SPARTACUS_DECLINE_COOP=1): every full problem of the orders 7..16 is declined by the
   // cooperative route and takes the second pass of the layer kernel (one lane, general eigen-solver) -
   // the path of units without the symmetric structure, which well-formed inputs hardly ever reach
-  int decline_cooperative;
+  int decline_cooperative;              // (2: the cooperative route runs and is then treated as not converged)
 };
 
 // canopy_flux_type members by index (order of radsurf_canopy_flux.F90:27-91,

@@ -272,8 +272,14 @@ __device__ __forceinline__ double group_sum(double x) {
 // One-sided (Hestenes) Jacobi, cyclic by rows; per rotation one inner product over the group (the
 // squared column norms are carried along: a' = a - t g, b' = b + t g, and recomputed at the start of
 // every sweep), the angle from fast reciprocals, the update of the own rows of W and Y.
+// A problem whose Jacobi iteration has not converged after the last sweep, or whose singular values are not
+// finite and positive (the fast reciprocals have no fix-up for zero norms), is handed to the second pass of
+// the layer kernel like a declined unit: status 0 and one more in the counter "one_lane_units" that wakes that
+// pass.  force_redo (diagnostic, SPARTACUS_DECLINE_COOP=2) does that to every problem AFTER the iteration, so
+// that the hand-over itself is covered by the goldens.
 template <int N, int G>
-SS_HD void coop_eig_unit(double* rec, long stride, int q) {
+SS_HD void coop_eig_unit(double* rec, long stride, int q, unsigned long long* one_lane_units = nullptr,
+                         bool force_redo = false) {
   constexpr int NR = (N + G - 1) / G;
   using Rec = EigRec<N>;
   if (!(rec_elem_load(rec, stride, Rec::STATUS) > 0.5)) return;   // same for the whole group
@@ -300,6 +306,7 @@ SS_HD void coop_eig_unit(double* rec, long stride, int q) {
   // the kernel).  The decision is taken on group-wide sums, so the lanes of a group agree on it.
   constexpr double tol = 4.0 * DBL_EPSILON;
   constexpr double tol_last = 1.0e-8;
+  bool still_rotating = true;
   for (int sweep = 0; sweep < 30; ++sweep) {
     SS_UNROLL_FULL
     for (int j = 0; j < N; ++j) {
@@ -342,16 +349,31 @@ SS_HD void coop_eig_unit(double* rec, long stride, int q) {
         }
       }
     }
-    if (!rotated) break;
+    if (!rotated) { still_rotating = false; break; }
   }
   // squared singular values; Y in place of W
+  bool bad = still_rotating || force_redo;
   SS_UNROLL_FULL
   for (int j = 0; j < N; ++j) {
     double s = 0.0;
     SS_UNROLL_FULL
     for (int r = 0; r < NR; ++r) s += w[r][j] * w[r][j];
     s = gsum(s);
+    if (!(s > 0.0 && s < 1.0e300)) bad = true;      // (the same on every lane of the group)
     if (q == (j % G)) rec_elem_store(rec, stride, Rec::EV + j, s);
+  }
+  if (bad) {
+    if (q == 0) {
+      rec_elem_store(rec, stride, Rec::STATUS, 0.0);
+      if (one_lane_units) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicAdd(one_lane_units, 1ULL);
+#else
+        *one_lane_units += 1ULL;
+#endif
+      }
+    }
+    return;
   }
   SS_UNROLL_FULL
   for (int r = 0; r < NR; ++r) {

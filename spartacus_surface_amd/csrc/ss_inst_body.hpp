@@ -70,7 +70,8 @@ __global__ void __launch_bounds__(kBlock, 1) k_eig_coop(const Launch L) {
   if (cu >= L.ncu) return;
   if (jlay >= L.in.nlay[L.cols[cu / L.nspec]]) return;
   if constexpr (coop_order(N))
-    coop_eig_unit<N, G>(L.eig + rec_base(jlay, L.maxlay, EigRec<N>::NELEM, cu), kRecStride, (int)threadIdx.x % G);
+    coop_eig_unit<N, G>(L.eig + rec_base(jlay, L.maxlay, EigRec<N>::NELEM, cu), kRecStride, (int)threadIdx.x % G,
+                        L.eigen_fail ? L.eigen_fail + kSlotOneLaneUnits : nullptr, L.cfg.decline_cooperative == 2);
 }
 
 // layer matrices + upward sweep of a column unit on one lane (orders that live in registers)

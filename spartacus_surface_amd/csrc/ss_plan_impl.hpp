@@ -744,7 +744,7 @@ class Plan {
     L.cfg.do_vegetation = cfg.do_vegetation;
     {
       const char* e = std::getenv("SPARTACUS_DECLINE_COOP");
-      L.cfg.decline_cooperative = (e && e[0] == '1') ? 1 : 0;
+      L.cfg.decline_cooperative = (e && e[0] == '1') ? 1 : (e && e[0] == '2') ? 2 : 0;
     }
     L.cols = d_index + c.dev_offset + first;
     L.ncols = (int)count;

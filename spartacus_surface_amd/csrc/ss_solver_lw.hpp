@@ -184,7 +184,7 @@ SS_HD void layer_first_lw(const Launch& L, int cu, int jlay, const W& w) {
   const bool full = !clear_only && !(p.frac[0] <= L.cfg.min_vegetation_fraction);
   double status = 0.0;
   if (full) {
-    if (gamma_structure_ok<NREG>(p.frac, fx) && !L.cfg.decline_cooperative) {
+    if (gamma_structure_ok<NREG>(p.frac, fx) && L.cfg.decline_cooperative != 1) {
       status = 1.0;
       rec_elem_store(erec, st, 1, p.g.dz);
       // the scalars Gamma1 and Gamma2 are built from (r16::gamma_rows builds the rows in k_pre16)

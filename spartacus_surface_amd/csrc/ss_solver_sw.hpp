@@ -205,7 +205,7 @@ SS_HD void layer_first_sw(const Launch& L, int cu, int jlay, const W& w) {
   double status = 0.0;
   int ierr = 0;
   if (full) {
-    if (gamma_structure_ok<NREG>(p.frac, p.fx) && !L.cfg.decline_cooperative) {
+    if (gamma_structure_ok<NREG>(p.frac, p.fx) && L.cfg.decline_cooperative != 1) {
       status = 1.0;
       // The direct-beam part of the unit (D x D: one lane does it for its unit here, the 16 lanes of
       // the row-of-16 kernel would each repeat it): int_dir and E go to the layer record, the

@@ -120,18 +120,21 @@ def test_golden_host_entry_chunk_pipeline(name, monkeypatch):
     assert not bad, "outside the parity bar: %s" % bad[:5]
 
 
+@pytest.mark.parametrize("how", ["1", "2"])
 @pytest.mark.parametrize("name", ["urban__4stream", "rami5__HET07_JPS_SUM-56-direct", "rami4pilps__vis-snw-0.3-2-4",
                                   "extra__urban-5stream"])
-def test_golden_with_cooperative_route_declined(name, monkeypatch):
+def test_golden_with_cooperative_route_declined(name, how, monkeypatch):
     """Orders 7..16: the second pass of the layer kernel (one lane per unit, general eigen-solver, on the
     plan's fallback stream) is where units without the symmetric structure go; well-formed inputs hardly
     ever reach it, so SPARTACUS_DECLINE_COOP=1 sends every full problem there.  Same goldens, same bar
-    (the upward and downward sweeps stay on DPP rows)."""
+    (the upward and downward sweeps stay on DPP rows).  =2 lets the cooperative route run and then treats every
+    Jacobi iteration as not converged: the hand-over of such a problem to the second pass (status 0 + counter,
+    csrc/ss_eigen_coop.hpp) is the same code a real non-convergence takes."""
     radsurf = _hip()
     have = [p for p in golden_files() if os.path.basename(p)[:-4] == name]
     if not have:
         pytest.skip("fixture not present")
-    monkeypatch.setenv("SPARTACUS_DECLINE_COOP", "1")
+    monkeypatch.setenv("SPARTACUS_DECLINE_COOP", how)
     case, expected = fixture_io.load_case(have[0])
     cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
     out = _alloc(case)
