@@ -163,20 +163,23 @@ def _urban_columns(rng, ncol, nsw, nlw):
     return base, cp, alb
 
 
-def c3_vegetated_urban(ncol=1_000_000, seed=12345, nstream=2):
+def c3_vegetated_urban(ncol=1_000_000, seed=12345, nstream=2, n_vegetation_region=2, tile=None):
     """C3: test/urban vegetated-urban column on 10 layers, 3 regions, 2 streams,
     1 SW + 1 LW band, SW+LW; per-column multiplicative jitter U(0.9,1.1) on
     building/vegetation fractions, scales and albedos (building+veg clipped to
-    0.98), cos_sza ~ U(0.05,1); temperatures of test_surfaces_in.nc."""
+    0.98), cos_sza ~ U(0.05,1); temperatures of test_surfaces_in.nc.
+    n_vegetation_region (1: two regions) and tile (ITileUrban: one region, the vegetation arrays are ignored)
+    give the other matrix orders on the same column set (parity tests of the orders 7, 8, 16)."""
     rng = np.random.default_rng(seed)
     cfg = Config(do_sw=True, do_lw=True, do_vegetation=True, do_urban=True,
-                 n_vegetation_region_forest=2, n_vegetation_region_urban=2, nsw=1, nlw=1,
+                 n_vegetation_region_forest=n_vegetation_region, n_vegetation_region_urban=n_vegetation_region,
+                 nsw=1, nlw=1,
                  n_stream_sw_forest=nstream, n_stream_sw_urban=nstream, n_stream_lw_forest=nstream,
                  n_stream_lw_urban=nstream).consolidate()
     L = 10
     base, cpa, alb = _urban_columns(rng, ncol, 1, 1)
     cp = CanopyProperties().set_layers(np.full(ncol, L, dtype=np.int32))
-    cp.i_representation = np.full(ncol, ITileVegetatedUrban, dtype=np.int32)
+    cp.i_representation = np.full(ncol, ITileVegetatedUrban if tile is None else tile, dtype=np.int32)
     cp.cos_sza = rng.uniform(0.05, 1.0, size=ncol)
     for k, v in cpa.items():
         setattr(cp, k, v.reshape(-1))

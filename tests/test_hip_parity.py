@@ -303,6 +303,18 @@ def test_synthetic_c3_four_streams_vs_oracle():
     assert not bad, bad[:5]
 
 
+@pytest.mark.parametrize("order,nveg,ns,urban_only", [(8, 1, 4, False), (16, 1, 8, False), (7, 2, 7, True)])
+def test_synthetic_other_row_orders_vs_oracle(order, nveg, ns, urban_only):
+    """The ends of the range of the row-of-16 kernels on the jittered C3 column set: order 8 (2 regions x 4
+    streams), 16 (2 x 8: all 16 lanes of a row live) and 7 (urban tile without vegetation, 1 region x 7 streams);
+    the goldens cover 9, 10, 12, 14 and 15."""
+    from spartacus_surface_amd import types, workloads
+    case = workloads.c3_vegetated_urban(ncol=256, seed=4321, nstream=ns, n_vegetation_region=nveg,
+                                        tile=types.ITileUrban if urban_only else None)
+    _, bad = _check_against_oracle(case, 256, "synthetic/c3_order%d_256" % order)
+    assert not bad, bad[:5]
+
+
 def test_synthetic_c4_four_streams_multiband_vs_oracle():
     """C4 with 4 streams: mixed forest / vegetated-urban columns, 14 SW + 16 LW bands, n = 12 in both tile kinds."""
     from spartacus_surface_amd import workloads
