@@ -406,6 +406,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--columns", type=int, default=1_000_000,
                     help="columns per GPU (weak scaling) or in total (strong scaling)")
+    ap.add_argument("--gather-bc-every-step", action="store_true",
+                    help="N > 1: also gather the four bc_out arrays to rank 0 after every step (off: the only "
+                         "exchange is the final gather of all flux members)")
     ap.add_argument("--workload", default="c3", choices=["c2", "c2r3ns8", "c3", "c3ns4", "c4", "c4ns4", "rami5"],
                     help="c3 (default) is the headline configuration; the others are extra lines")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -457,10 +460,15 @@ def main():
     cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
     plan = radsurf.Plan(cfg, cp, sw, lw, want_profiles=False)   # inputs now resident in HBM
 
+    # The path has ONE exchange step (north_star: "RCCL over xGMI only for the final flux gather"):
+    # every flux member to rank 0 after the last step, inside the timed region.  The steps themselves involve no
+    # collective and no synchronisation, exactly as at N = 1 (columns are independent).  --gather-bc-every-step
+    # adds what a host atmosphere model that runs on rank 0 would need after every step (the four bc_out arrays).
     gather_bc = gather_all = None
     if world > 1:
         bc_names = ["bc_out." + n for n in ("sw_albedo", "sw_albedo_dir", "lw_emissivity", "lw_emission")]
-        gather_bc = distributed.DeviceGather(plan, dist, cp.ncol, cp.ntotlay, names=bc_names, stage_host=rehearsal)
+        if args.gather_bc_every_step:
+            gather_bc = distributed.DeviceGather(plan, dist, cp.ncol, cp.ntotlay, names=bc_names, stage_host=rehearsal)
         gather_all = distributed.DeviceGather(plan, dist, cp.ncol, cp.ntotlay, stage_host=rehearsal)
 
     def step():
@@ -565,8 +573,9 @@ def main():
                                     "GB/s_into_rank0": (world - 1) * gather_all.bytes_per_rank
                                     / (final_gather_ms * 1e-3) / 1e9 if final_gather_ms else None,
                                     "note": "bc_out + every allocated member of the four flux objects, device to "
-                                            "device over RCCL, once after the last step, inside the timed region; "
-                                            "bc_out alone after every step"}
+                                            "device over RCCL, once after the last step, inside the timed region"
+                                            + ("; bc_out alone after every step" if args.gather_bc_every_step else
+                                               "; no exchange and no synchronisation between the steps")}
         if world == 1 and not args.no_extras and case.get("top_flux_dn_sw") is not None:
             line["scale_sum"] = scale_sum_rate(plan, case, my_cols)
         if world == 1 and not args.no_cpu_baseline and not args.no_extras:
