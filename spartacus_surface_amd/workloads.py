@@ -213,6 +213,25 @@ def c3_vegetated_urban(ncol=1_000_000, seed=12345, nstream=2, n_vegetation_regio
                    top_flux_dn_lw=np.full((ncol, 1), StefanBoltzmann * t_sky ** 4))
 
 
+def with_more_layers(case, extra):
+    """The same columns with their lowest `extra` layers repeated on top (a test input: columns deeper than
+    the 10 layers of the bench workloads, e.g. for the paths of the kernels that depend on the layer count)."""
+    from . import abi
+    cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
+    ncol = cp.ncol
+    L = int(cp.nlay[0])
+    assert np.all(np.asarray(cp.nlay) == L) and 0 < extra <= L
+    for obj, names in ((cp, abi.CANOPY_REAL_FIELDS), (sw, abi.SW_FIELDS), (lw, abi.LW_FIELDS)):
+        for n in names:
+            a = getattr(obj, n)
+            if a is not None and a.shape[0] == ncol * L:
+                b = a.reshape((ncol, L) + a.shape[1:])
+                b = np.concatenate([b, b[:, :extra]], axis=1)
+                setattr(obj, n, np.ascontiguousarray(b.reshape((ncol * (L + extra),) + a.shape[1:])))
+    cp.set_layers(np.full(ncol, L + extra, dtype=np.int32))
+    return case
+
+
 def c4_mixed(ncol=1_000_000, seed=12345, nsw=14, nlw=16, nstream=2):
     """C4: 50/50 forest (10 layers, 3 regions, `nstream` streams) and C3-like vegetated
     urban columns, 14 SW + 16 LW bands.  SW band values from the rami5 HET09

@@ -78,3 +78,20 @@ def test_emulated_ragged_all_tile_types_vs_oracle(emul):
     bad = fixture_io.parity_violations(fixture_io.flatten_outputs(out), ref, noise, truth=truth,
                                        noise_arr=noise_arr, slack=2.0)
     assert not bad, bad[:5]
+
+
+def test_emulated_deep_columns_vs_oracle(emul):
+    """14-layer columns: more layers than the per-lane slots of the downward sweeps can stage for every field
+    (csrc/ss_column_sw.hpp: PUTL), so staged and directly stored fields mix."""
+    from oracle import checker
+    from spartacus_surface_amd import workloads
+    case = workloads.with_more_layers(workloads.c3_vegetated_urban(ncol=24, seed=777), 4)
+    a = (case["config"], case["canopy"], case["sw"], case["lw"])
+    out, nfail = emul.run_emul(*a, want_profiles=False)
+    assert nfail == 0
+    ref = fixture_io.flatten_outputs(checker.run_oracle(*a, want_profiles=False)[0])
+    truth = fixture_io.flatten_outputs(checker.run_oracle(*a, want_profiles=False, quad=True)[0])
+    noise, noise_arr = fixture_io.noise_from_truth(ref, truth)
+    bad = fixture_io.parity_violations(fixture_io.flatten_outputs(out), ref, noise, truth=truth,
+                                       noise_arr=noise_arr, slack=2.0)
+    assert not bad, bad[:5]

@@ -315,6 +315,15 @@ def test_synthetic_other_row_orders_vs_oracle(order, nveg, ns, urban_only):
     assert not bad, bad[:5]
 
 
+def test_synthetic_c3_fourteen_layers_vs_oracle():
+    """Columns deeper than the per-lane LDS slots of the downward sweeps can stage (80 slots: 8 fields x 10
+    layers): with 14 layers only five fields are staged and the others are stored as they are computed."""
+    from spartacus_surface_amd import workloads
+    case = workloads.with_more_layers(workloads.c3_vegetated_urban(ncol=512, seed=777), 4)
+    _, bad = _check_against_oracle(case, 512, "synthetic/c3_14layers_512")
+    assert not bad, bad[:5]
+
+
 def test_synthetic_c4_four_streams_multiband_vs_oracle():
     """C4 with 4 streams: mixed forest / vegetated-urban columns, 14 SW + 16 LW bands, n = 12 in both tile kinds."""
     from spartacus_surface_amd import workloads
