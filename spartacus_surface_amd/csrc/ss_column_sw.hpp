@@ -27,13 +27,18 @@ namespace ss {
 template <int N, int D>
 struct SwColRec {
   static constexpr int PDN = 0;                           // P = Den^-1 T      N x N
-  static constexpr int QDN = PDN + rec_even(N * N);       // Q = Den^-1 (R d_above E + S_dn)  N x D
-  static constexpr int ABE = QDN + rec_even(N * D);       // a_below(l+1)      N x N (canopy part)
+  // (sw_dirvec, ss_layer_matrices.hpp: Q and d_below already applied to the direct flux at the top of the layer)
+  static constexpr bool DIRVEC = sw_dirvec(N);
+  static constexpr int NQ = DIRVEC ? N : N * D;
+  static constexpr int QDN = PDN + rec_even(N * N);       // Q = Den^-1 (R d_above E + S_dn)  N x D  [or Q dir_top]
+  static constexpr int ABE = QDN + rec_even(NQ);          // a_below(l+1)      N x N (canopy part)
   // a_below is symmetric in the scaled coordinates of its layer (reciprocity): the small orders store
   // D^-1 a_below D as a packed lower triangle (sym_packed, ss_layer_matrices.hpp)
   static constexpr bool PACKED = sym_packed_col(N, false);
   static constexpr int NAB = PACKED ? tri_count(N) : N * N;
-  static constexpr int DBE = ABE + rec_even(NAB);         // d_below(l+1)      N x D (canopy part)
+  static constexpr int DBE = ABE + rec_even(NAB);         // d_below(l+1)      N x D (canopy part)  [or d_below dir_top]
+  static constexpr int DTP = DBE + rec_even(NQ);          // DIRVEC: direct flux at the top of the layer, D (written by
+                                                          // the first, downward stage of the upward kernel)
   // fused layer + upward kernel (fused_order(N)): no layer record exists, and what the downward
   // sweep reads of it travels in the column record: trans_dir_dir (E) and int_dir, D x D each
   static constexpr bool FUSED = fused_order(N, false);
@@ -46,7 +51,7 @@ struct SwColRec {
   static constexpr int EDIR = DBE + rec_even(N * D);
 #endif
   static constexpr int IDIR = EDIR + rec_even(D * D);
-  static constexpr int NELEM = FUSED ? IDIR + rec_even(D * D) : DBE + rec_even(N * D);
+  static constexpr int NELEM = FUSED ? IDIR + rec_even(D * D) : DIRVEC ? DTP + rec_even(D) : DBE + rec_even(N * D);
   // Den = I - a_above R.  The downward sweep needs the flux at the layer base,
   //   diff_base = Den^-1 (T diff_top + R d_above E dir_top + S_dn dir_top) = P diff_top + Q dir_top,
   // so the two operators are stored instead of LU(Den): the sweep then reads
@@ -504,7 +509,13 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
     }
     apply_V_vec<NREG, DB, NS>(V, diff_ab, diff_below);
     abe_matvec(ABE, lo[0], lo[1], diff_below, up_below);
-    mat_vec_acc<N, D>(DBE, dir_below, up_below);
+    if constexpr (CRec::DIRVEC) {
+      // d_below dir_below, formed by the upward kernel (zero in the pass without a direct beam)
+      SS_UNROLL_N(N)
+      for (int i = 0; i < N; ++i) up_below[i] = up_below[i] + (dirpass ? DBE[i] : 0.0);
+    } else {
+      mat_vec_acc<N, D>(DBE, dir_below, up_below);
+    }
     if (URBAN) {
       // exposed roof (urban :717-721): a_below / d_below roof blocks
       const double roof_a = lo[2];
@@ -528,10 +539,10 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
   if (nlay > 0) {
     const int jlay = nlay - 1;
     const double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
-    double ABE[NABE], DBE[N * D];
+    double ABE[NABE], DBE[CRec::NQ];
     din.load_pack(pack_rec(L, jlay, cu, kPackSw));
     rec_load<NABE>(crec, st, CRec::ABE, ABE);
-    rec_load<N * D>(crec, st, CRec::DBE, DBE);
+    rec_load<CRec::NQ>(crec, st, CRec::DBE, DBE);
     SS_LOAD_FENCE();
     const double lo[4] = {din.g.veg_fraction, din.g.building_fraction, din.roof_albedo, din.roof_albedo_dir};
     cross(lo, true, 0.0, 0.0, ABE, DBE, dir_above, diff_above, dir_below, diff_below, up_below, nullptr);
@@ -546,10 +557,10 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
     const LayerGeom g = dcur.g;
 
     // ---- issue group 2 (E, Q), work on the fluxes just below the top interface ----
-    double E[D * D], Q[N * D];
+    double E[D * D], Q[CRec::NQ];
     if (CRec::FUSED) rec_load<D * D>(crec, st, CRec::EDIR, E);
     else rec_load<D * D>(lrec, st, LRec::EDIR, E);
-    rec_load<N * D>(crec, st, CRec::QDN, Q);
+    rec_load<CRec::NQ>(crec, st, CRec::QDN, Q);
     SS_LOAD_FENCE();
 
     if (URBAN) {
@@ -587,10 +598,15 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
       for (int r = 0; r < D; ++r) { dir_above[r] = t[r]; dir_conv[r] = dir_below[r] - t[r]; }
     }
     double t3[N];
-    mat_vec<N, D>(Q, dir_below, t3);
+    if constexpr (CRec::DIRVEC) {
+      SS_UNROLL_N(N)
+      for (int i = 0; i < N; ++i) t3[i] = dirpass ? Q[i] : 0.0;     // Q dir_below, formed by the upward kernel
+    } else {
+      mat_vec<N, D>(Q, dir_below, t3);
+    }
 
     // ---- issue group 4 (a_below, d_below and the scalars of the layer below; int_dir), work on group 3 ----
-    double ABE[NABE], DBE[N * D], IDIR[D * D];
+    double ABE[NABE], DBE[CRec::NQ], IDIR[D * D];
     double lo[4] = {0.0, 0.0, 0.0, 0.0};
     if (jlay > 0) {
       const double* crec_n = L.col + rec_base(jlay - 1, L.maxlay, CRec::NELEM, cu);
@@ -600,7 +616,7 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
       lo[2] = ra.x;
       lo[3] = ra.y;
       rec_load<NABE>(crec_n, st, CRec::ABE, ABE);
-      rec_load<N * D>(crec_n, st, CRec::DBE, DBE);
+      rec_load<CRec::NQ>(crec_n, st, CRec::DBE, DBE);
     }
     if (CRec::FUSED) rec_load<D * D>(crec, st, CRec::IDIR, IDIR);
     else rec_load<D * D>(lrec, st, LRec::IDIR, IDIR);

@@ -61,7 +61,7 @@ SS_HD void sw_ground(const LG& lg, double ga, double gad, double cos_sza, const 
 template <int N, int D, class Src>
 SS_HD void sw_adding_step(const Src& src, const Src* next, double* R, double* T, const double* Aab,
                           const double* Dab, double* crec, const double* dsc, const double* rd, double* Abe,
-                          double* Dbe) {
+                          double* Dbe, const double* dtop = nullptr) {
   using LRec = SwLayRec<N, D>;
   using CRec = SwColRec<N, D>;
   static_assert(LRec::PACKED, "packed layer record");
@@ -167,7 +167,20 @@ SS_HD void sw_adding_step(const Src& src, const Src* next, double* R, double* T,
       SS_UNROLL_FULL
       for (int i = 0; i < N; ++i) SS_E(Q, i, j, N) *= dsc[i];
     }
-    rec_store<N * D>(crec, st, CRec::QDN, Q);
+    if constexpr (CRec::DIRVEC) {
+      // Q dir_top (dtop: the direct flux at the top of this layer, column_up_sw's first stage)
+      double qd[N];
+      SS_UNROLL_FULL
+      for (int i = 0; i < N; ++i) {
+        double a = 0.0;
+        SS_UNROLL_FULL
+        for (int j = 0; j < D; ++j) a += SS_E(Q, i, j, N) * dtop[j];
+        qd[i] = a;
+      }
+      rec_store<N>(crec, st, CRec::QDN, qd);
+    } else {
+      rec_store<N * D>(crec, st, CRec::QDN, Q);
+    }
   }
   SS_UNROLL_FULL
   for (int j = 0; j < D; ++j) {
@@ -210,7 +223,76 @@ SS_HD void sw_adding_step(const Src& src, const Src* next, double* R, double* T,
     SS_UNROLL_FULL
     for (int i = 0; i < N; ++i) SS_E(S, i, j, N) = dsc[i] * SS_E(Dbe, i, j, N);
   }
-  rec_store<N * D>(crec, st, CRec::DBE, S);
+  if constexpr (CRec::DIRVEC) {
+    double dd[N];
+    SS_UNROLL_FULL
+    for (int i = 0; i < N; ++i) {
+      double a = 0.0;
+      SS_UNROLL_FULL
+      for (int j = 0; j < D; ++j) a += SS_E(S, i, j, N) * dtop[j];
+      dd[i] = a;
+    }
+    rec_store<N>(crec, st, CRec::DBE, dd);
+  } else {
+    rec_store<N * D>(crec, st, CRec::DBE, S);
+  }
+}
+
+// First stage of the upward kernel where the column record is in its DIRVEC form: the direct flux at the top of
+// every layer for a unit direct beam on the horizontal at canopy top (the pass the downward kernel normalises
+// by the direct flux), top down - through the overlap rules at every interface and the direct transmittance E
+// of every layer, exactly the recursion of column_down_sw -, into element DTP of the column records.
+template <bool URBAN, int NREG, int NS>
+SS_HD void sw_direct_tops(const Launch& L, int cu, int nlay, double cos_sza) {
+  constexpr int N = NREG * NS, D = NREG;
+  constexpr int DB = URBAN ? NREG + 1 : NREG;
+  using LRec = SwLayRec<N, D>;
+  using CRec = SwColRec<N, D>;
+  constexpr long st = kRecStride;
+  double dir_ab[D];
+  dir_ab[0] = 1.0 / cos_sza;
+  SS_UNROLL_FULL
+  for (int r = 1; r < D; ++r) dir_ab[r] = 0.0;
+  double vf_up = 0.0, bf_up = 0.0;
+  double E[D * D], vf_lo = 0.0, bf_lo = 0.0;
+  if (nlay > 0) {
+    rec_load<D * D>(L.lay + rec_base(nlay - 1, L.maxlay, LRec::NELEM, cu), st, LRec::EDIR, E);
+    pack_fractions(pack_rec(L, nlay - 1, cu, kPackSw), vf_lo, bf_lo);
+  }
+  for (int jl = nlay - 1; jl >= 0; --jl) {
+    // (what the next layer down needs is requested a step ahead)
+    double En[D * D], vf_n = 0.0, bf_n = 0.0;
+    if (jl > 0) {
+      rec_load<D * D>(L.lay + rec_base(jl - 1, L.maxlay, LRec::NELEM, cu), st, LRec::EDIR, En);
+      pack_fractions(pack_rec(L, jl - 1, cu, kPackSw), vf_n, bf_n);
+    }
+    SS_LOAD_FENCE(); SS_SCHED_FENCE();
+    double U[NREG * DB], V[DB * NREG];
+    interface_overlap_vals<URBAN, false, NREG>(L.cfg.min_vegetation_fraction, jl + 1 >= nlay, vf_up, bf_up, false,
+                                               vf_lo, bf_lo, U, V);
+    double db[D];
+    SS_UNROLL_FULL
+    for (int k = 0; k < D; ++k) {
+      double a = 0.0;
+      SS_UNROLL_FULL
+      for (int ju = 0; ju < NREG; ++ju) a += SS_E(V, k, ju, DB) * dir_ab[ju];
+      db[k] = a;
+    }
+    rec_store<D>(L.col + rec_base(jl, L.maxlay, CRec::NELEM, cu), st, CRec::DTP, db);
+    SS_UNROLL_FULL
+    for (int r = 0; r < D; ++r) {
+      double a = 0.0;
+      SS_UNROLL_FULL
+      for (int k = 0; k < D; ++k) a += SS_E(E, r, k, D) * db[k];
+      dir_ab[r] = a;
+    }
+    SS_UNROLL_FULL
+    for (int k = 0; k < D * D; ++k) E[k] = En[k];
+    vf_up = vf_lo;
+    bf_up = bf_lo;
+    vf_lo = vf_n;
+    bf_lo = bf_n;
+  }
 }
 
 // Overlap to the base of the layer above layer jlay, or to the free atmosphere (forest :495-503, urban
@@ -352,6 +434,7 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
     region_roots<NREG>(frac, sf, rsf);
   }
   sym::sw_ground<NREG, NS>(L.lg, in.ground_albedo[c.cidx], in.ground_albedo_dir[c.cidx], c.cos_sza, rsf, Aab, Dab);
+  if constexpr (CRec::DIRVEC) sw_direct_tops<URBAN, NREG, NS>(L, cu, c.nlay, c.cos_sza);
   double R[rec_even(kTri<N>)], T[rec_even(kTri<N>)];
 #if !defined(SS_NO_COLUMN_PREFETCH)
   if (c.nlay > 0) {
@@ -365,6 +448,8 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
     const RecSource lnext{L.lay + rec_base(jlay + 1, L.maxlay, LRec::NELEM, cu), kRecStride};
     double* crec = L.col + rec_base(jlay, L.maxlay, CRec::NELEM, cu);
     SwOverlapIn oi;
+    double dtop[rec_even(D)] = {0.0};
+    if constexpr (CRec::DIRVEC) rec_load<D>(crec, kRecStride, CRec::DTP, dtop);
 #if defined(SS_NO_COLUMN_PREFETCH)
     lrec.template load<rec_even(kTri<N>)>(LRec::R, R);
     lrec.template load<rec_even(kTri<N>)>(LRec::T, T);
@@ -381,7 +466,7 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
       }
     }
     double Abe[kTri<N>], Dbe[N * D];
-    sym::sw_adding_step<N, D>(lrec, jlay + 1 < c.nlay ? &lnext : nullptr, R, T, Aab, Dab, crec, dsc, rd, Abe, Dbe);
+    sym::sw_adding_step<N, D>(lrec, jlay + 1 < c.nlay ? &lnext : nullptr, R, T, Aab, Dab, crec, dsc, rd, Abe, Dbe, dtop);
 #if defined(SS_NO_COLUMN_PREFETCH)
     oi.template load<URBAN>(L, cu, jlay, c.nlay);
 #endif

@@ -106,6 +106,21 @@ constexpr bool sym_packed_col(int nf, bool lw) { return lw && sym_packed(nf, lw)
 #else
 constexpr bool sym_packed_col(int nf, bool lw) { return sym_packed(nf, lw); }
 #endif
+// Shortwave column record of the small orders: the two direct-beam blocks of a layer, Q (N x D: diffuse flux at the
+// base per unit of direct flux in each region at the top) and d_below (N x D), are only ever applied to ONE
+// vector in the downward sweep - the direct flux at the top of that layer in the pass normalised by the direct
+// beam -, and that vector follows from the direct transmittances E and the overlap rules alone.  The upward
+// sweep therefore runs that recursion first (top down, 3 x 3 work) and stores Q dir_top and d_below dir_top,
+// N numbers each, instead of the 2 N D of the blocks: 94 -> 74 doubles per unit-layer written and read
+// (-DSS_NO_SW_DIRVEC: the blocks).
+constexpr bool fused_order(int n, bool lw);
+constexpr bool sw_dirvec(int n) {
+#if defined(SS_NO_SW_DIRVEC)
+  return false && n > 0;
+#else
+  return sym_packed_col(n, false) && !fused_order(n, false);
+#endif
+}
 constexpr int tri_count(int n) { return n * (n + 1) / 2; }
 // packed lower triangle, column by column: index of (i, j), i >= j, and back
 constexpr int tri_index(int n, int i, int j) { return i + j * n - j * (j + 1) / 2; }

@@ -90,7 +90,9 @@ inline int col_nelem(bool lw, const ClassKey& k) {
   auto ev = [](int x) { return (x + 1) & ~1; };
   // a_below is packed (scaled, symmetric) for the small orders
   const int ab = sym_packed_col(n, lw) ? tri_count(n) : n * n;
-  const int base = lw ? ev(n * n) + ev(ab) + 2 * ev(n) : ev(n * n) + ev(ab) + 2 * ev(n * d);
+  // (shortwave, small orders: Q and d_below applied to the direct flux at the layer top, + that flux: sw_dirvec)
+  const int base = lw ? ev(n * n) + ev(ab) + 2 * ev(n)
+                      : sw_dirvec(n) ? ev(n * n) + ev(ab) + 2 * ev(n) + ev(d) : ev(n * n) + ev(ab) + 2 * ev(n * d);
   if (!fused_order(n, lw)) return base;
 #if defined(SS_FUSE_VIA_RECORD)
   return base + (lw ? ev(n * n) + ev(n) : 2 * ev(d * d) + 2 * ev(n * d));
