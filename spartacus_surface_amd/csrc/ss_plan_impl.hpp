@@ -633,7 +633,12 @@ class Plan {
     const size_t per_col = (size_t)nspec * c.maxlay * sizeof(double)
                            * (lay_nelem(lw, c.key) + col_nelem(lw, c.key) + eig_nelem(c.key));
     size_t chunk = std::max<size_t>(1, scratch_budget_bytes / std::max<size_t>(1, per_col));
-    if (chunks_per_pipe > 0) {
+    // (classes that stay on one pipe - orders above 16, whose kernels keep their matrices in the hardware scratch
+    // and want launches as large as the budget allows - are cut by the budget alone: measured on the order-24
+    // workload, 8.7e5 columns/s against 3.2e5 with 16 384-unit chunks)
+    const int order = c.key.nreg * c.key.ns;
+    const bool one_pipe = order > SS_UNROLL_MAX && !coop_order(order);
+    if (chunks_per_pipe > 0 && !one_pipe) {
       // (counted for the default number of pipes, so that the chunk size - and with it the size of the
       // scratch buffers - does not depend on set_pipes())
       const size_t parts = (size_t)chunks_per_pipe * (size_t)kDefaultPipes;
