@@ -145,6 +145,8 @@ struct LaneLds<false> {
 
 // doubles per (unit, layer) of the input pack (ss_pack.hpp)
 constexpr int kPackSw = 16, kPackLw = 18;
+constexpr double kPackNoLayer = -2.0;   // element 15 of a shortwave pack record (else cos_sza), element 0 of a
+                                        // longwave one (else dz): the column has no such layer
 
 constexpr double kPi = 3.14159265358979323846;   // radtool/radiation_constants.F90:24
 constexpr double kStefanBoltzmann = 5.67037321e-8;  // radiation_constants.F90:26

@@ -14,7 +14,8 @@
 //
 //   SW (kPackSw = 16): dz, veg_fraction | veg_scale, veg_ext | veg_fsd, building_fraction |
 //                      building_scale, veg_contact_fraction | roof_albedo, roof_albedo_dir |
-//                      wall_albedo, air_ext | air_ssa, veg_ssa | wall_specular_frac, -
+//                      wall_albedo, air_ext | air_ssa, veg_ssa | wall_specular_frac, cos_sza of the column
+//                      (kPackNoLayer where the column has no such layer)
 //   LW (kPackLw = 18): the same four geometry pairs | air_ext, air_ssa | veg_ssa, veg_planck |
 //                      veg_air_planck, clear_air_planck | roof_emissivity, roof_emission |
 //                      wall_emissivity, wall_emission
@@ -40,7 +41,13 @@ SS_HD void pack_unit(const PackLaunch& P, int cu, int jlay) {
   const Inputs& in = P.in;
   const int col = P.cols[cu / P.nspec];
   const int jb = cu % P.nspec;
-  if (jlay >= in.nlay[col]) return;
+  if (jlay >= in.nlay[col]) {
+    // a layer slot the column does not have: marked in the last shortwave element, which otherwise carries the
+    // column's cos_sza - so that the layer kernel needs no look-up through the column index before it starts
+    if (!P.lw) rec_pair_store(P.pack + rec_base(jlay, P.maxlay, kPackSw, cu) + 14 * kRecStride, 0.0, kPackNoLayer);
+    else rec_pair_store(P.pack + rec_base(jlay, P.maxlay, kPackLw, cu), kPackNoLayer, 0.0);   // longwave: in dz's place
+    return;
+  }
   const int lay = in.istartlay[col] - 1 + jlay;
   const long sidx = (long)jb + (long)P.nspec * lay;
   const bool veg = P.nreg > 1, urban = P.urban != 0;
@@ -55,7 +62,7 @@ SS_HD void pack_unit(const PackLaunch& P, int cu, int jlay) {
     rec_pair_store(r + 8 * st, urban ? in.roof_albedo[sidx] : 0.0, urban ? in.roof_albedo_dir[sidx] : 0.0);
     rec_pair_store(r + 10 * st, urban ? in.wall_albedo[sidx] : 0.0, in.air_ext[sidx]);
     rec_pair_store(r + 12 * st, in.air_ssa[sidx], veg ? in.veg_ssa[sidx] : 0.0);
-    rec_pair_store(r + 14 * st, urban ? in.wall_specular_frac[sidx] : 0.0, 0.0);
+    rec_pair_store(r + 14 * st, urban ? in.wall_specular_frac[sidx] : 0.0, in.cos_sza ? in.cos_sza[col] : 0.0);
   } else {
     rec_pair_store(r + 8 * st, in.air_ext[sidx], in.air_ssa[sidx]);
     rec_pair_store(r + 10 * st, veg ? in.veg_ssa[sidx] : 0.0, veg ? in.veg_planck[sidx] : 0.0);

@@ -268,7 +268,19 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
   const LG& lg = L.lg;
   const int col = L.cols[cu / L.nspec];
   const int jb = cu % L.nspec;
-  if (jlay >= in.nlay[col]) return;
+  // (the pack record is requested together with the column index, before the layer count can say whether this
+  // unit exists: see layer_unit_sw)
+  LwLayerIn<URBAN, NREG> raw;
+  double wall_emis1 = 0.0;
+  constexpr bool kEarlyPack = (STAGE == 0) || !r16_layer(NREG * NS, true);
+  if constexpr (kEarlyPack) {
+    raw.load_pack(pack_rec(L, jlay, cu, kPackLw));
+    if (URBAN) wall_emis1 = rec_pair_load(pack_rec(L, jlay, cu - jb, kPackLw) + 16 * kRecStride).x;
+    SS_LOAD_FENCE();
+    if (raw.g.dz == kPackNoLayer) return;      // (the pack record says whether the column has this layer: ss_pack.hpp)
+  } else {
+    if (jlay >= in.nlay[col]) return;
+  }
   if constexpr (STAGE == 1 && r16_layer(NREG * NS, true)) {
     layer_first_lw<URBAN, NREG, NS>(L, cu, jlay, w);
     return;
@@ -280,8 +292,10 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
   }
 
   // per-layer inputs from the input pack (ss_pack.hpp)
-  LwLayerIn<URBAN, NREG> raw;
-  raw.load_pack(pack_rec(L, jlay, cu, kPackLw));
+  if constexpr (!kEarlyPack) {
+    raw.load_pack(pack_rec(L, jlay, cu, kPackLw));
+    if (URBAN) wall_emis1 = rec_pair_load(pack_rec(L, jlay, cu - jb, kPackLw) + 16 * kRecStride).x;
+  }
   LwLayerProps<URBAN, NREG> p;
   lw_layer_props<URBAN, NREG>(L, raw, p);
   double fx[NREG * NREG];
@@ -291,8 +305,7 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
   // bands (radsurf_urban_lw.F90:390-392)
   const double wall_ext = 1.0;
   // (band 1 = the pack record of the column's first unit, element 16 = wall_emissivity)
-  const double wall_factor =
-      URBAN ? 1.0 - rec_pair_load(pack_rec(L, jlay, cu - jb, kPackLw) + 16 * kRecStride).x : 0.0;
+  const double wall_factor = URBAN ? 1.0 - wall_emis1 : 0.0;
 
   double g1[N * N], g2[N * N], b[N];
   mat_zero<N, N>(g1);

@@ -288,7 +288,28 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
   const Inputs& in = L.in;
   const int col = L.cols[cu / L.nspec];
   const int jb = cu % L.nspec;
-  if (jlay >= in.nlay[col]) return;
+  // The pack record of (cu, jlay) exists for every layer slot of the tile, whether the column has that layer or
+  // not, and its address does not depend on the column: its loads are requested together with the column
+  // index (it used to wait for the column index and then for the layer count: three dependent round trips at
+  // the start of every wave).
+  double pk[kPackSw];
+  constexpr bool kEarlyPack = (STAGE == 0) || !r16_layer(NREG * NS, false);
+  if constexpr (kEarlyPack) {
+    rec_load<kPackSw>(pack_rec(L, jlay, cu, kPackSw), kRecStride, 0, pk);
+    SS_LOAD_FENCE();
+  }
+  double cos_in;
+  if constexpr (kEarlyPack) {
+    // ... and the pack record itself says whether the layer exists and carries the column's cos_sza (ss_pack.hpp):
+    // ONE round trip before the arithmetic starts
+    if (pk[15] == kPackNoLayer) return;
+    cos_in = pk[15];
+  } else {
+    const int nlay_col = in.nlay[col];
+    cos_in = in.cos_sza[col];
+    SS_LOAD_FENCE();
+    if (jlay >= nlay_col) return;
+  }
   if constexpr (STAGE == 1 && r16_layer(NREG * NS, false)) {
     layer_first_sw<URBAN, NREG, NS>(L, cu, jlay, w);
     return;
@@ -299,7 +320,6 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
                       EigRec<NREG * NS>::STATUS) != 0.0) return;      // 1: row-of-16 kernels, -1: first pass
   }
 
-  const double cos_in = in.cos_sza[col];
   const double cos_sza = URBAN ? ss_max(cos_in, 1.0e-6) : cos_in;
   double sin0 = 0.0, tan0;
   if (URBAN) {
@@ -310,8 +330,7 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
   }
 
   // per-layer inputs from the input pack (ss_pack.hpp)
-  double pk[kPackSw];
-  rec_load<kPackSw>(pack_rec(L, jlay, cu, kPackSw), kRecStride, 0, pk);
+  if constexpr (!kEarlyPack) rec_load<kPackSw>(pack_rec(L, jlay, cu, kPackSw), kRecStride, 0, pk);
   LayerGeom g;
   g.dz = pk[0]; g.veg_fraction = pk[1]; g.veg_scale = pk[2]; g.veg_ext = pk[3];
   g.veg_fsd = pk[4]; g.building_fraction = pk[5]; g.building_scale = pk[6]; g.veg_contact_fraction = pk[7];
