@@ -360,9 +360,17 @@ struct SwDownIn {
   // The same from the input pack (ss_pack.hpp).  The *_t members (band itransp) are
   // only used by the lane whose band IS itransp (sunlit fractions), for which they
   // equal its own air_ext / veg_ssa.
+  SS_HD void load_pack(const RecView& pv, int jlay) {
+    double v[kPackSw];
+    pv.template load<kPackSw>(jlay, 0, v);
+    set_pack(v);
+  }
   SS_HD void load_pack(const double* prec) {
     double v[kPackSw];
     rec_load<kPackSw>(prec, kRecStride, 0, v);
+    set_pack(v);
+  }
+  SS_HD void set_pack(const double* v) {
     wall_specular_frac = v[14];
     g.dz = v[0]; g.veg_fraction = v[1]; g.veg_scale = v[2]; g.veg_ext = v[3];
     g.veg_fsd = v[4]; g.building_fraction = v[5]; g.building_scale = v[6]; g.veg_contact_fraction = v[7];

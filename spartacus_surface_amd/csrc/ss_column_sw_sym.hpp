@@ -16,6 +16,7 @@
 #pragma once
 
 #include "ss_column_sw.hpp"
+#include "ss_down_sw_both.hpp"
 #include "ss_layer_sym.hpp"
 
 namespace ss {
@@ -555,8 +556,12 @@ template <bool URBAN, int NREG, int NS>
 SS_HD void column_unit_sw(const Launch& L, int cu) {
   if constexpr (SwColRec<NREG * NS, NREG>::FUSED) layer_up_sw_any<URBAN, NREG, NS>(L, cu);
   else column_up_sw<URBAN, NREG, NS>(L, cu);
-  column_down_sw<URBAN, NREG, NS>(L, cu, 0);
-  column_down_sw<URBAN, NREG, NS>(L, cu, 1);
+  if constexpr (sw_down_both(NREG * NS)) {
+    column_down_sw_both<URBAN, NREG, NS>(L, cu);
+  } else {
+    column_down_sw<URBAN, NREG, NS>(L, cu, 0);
+    column_down_sw<URBAN, NREG, NS>(L, cu, 1);
+  }
 }
 
 }  // namespace ss

@@ -256,6 +256,26 @@ struct Launch {
   FluxDev flux_b;        // sw_norm_diff / lw_norm
   unsigned long long* eigen_fail;   // count of non-converged eigenproblems
 };
+// The launch descriptor as the kernel-argument segment holds it, through a pointer the optimiser cannot see
+// through: what is read from it HERE is loaded here (s_load from the constant address space) instead of being
+// hoisted to the kernel entry and kept - or spilled, lane by lane, into VGPRs - across a loop that only needs it
+// at its end.  The downward kernels read the 54 member pointers of the two flux objects this way; every kernel
+// that uses it takes the descriptor as its only argument, by value.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) Launch* ss_kernarg_launch_ptr;
+#define SS_LAUNCH_HERE(L, name) ss_kernarg_launch_ptr name##_p_ = (ss_kernarg_launch_ptr)__builtin_amdgcn_kernarg_segment_ptr(); \
+  asm volatile("" : "+s"(name##_p_)); \
+  const __attribute__((address_space(4))) Launch& name = *name##_p_
+// the same as a plain reference (what functions that take const Launch& / const LG& accept); after inlining the
+// loads are still scalar loads from the constant address space
+#define SS_LAUNCH_HERE_REF(L, name) ss_kernarg_launch_ptr name##_p_ = (ss_kernarg_launch_ptr)__builtin_amdgcn_kernarg_segment_ptr(); \
+  asm volatile("" : "+s"(name##_p_)); \
+  const Launch& name = *(const Launch*)name##_p_
+#else
+#define SS_LAUNCH_HERE(L, name) const Launch& name = (L)
+#define SS_LAUNCH_HERE_REF(L, name) const Launch& name = (L)
+#endif
+
 // Counter slot (of the buffer behind Launch::eigen_fail, zeroed at the start of every solve) that the
 // first pass of the layer kernel of the cooperative orders sets when it meets a unit the cooperative
 // route does not take (a sub-problem, or no symmetric structure): as long as it is zero the second

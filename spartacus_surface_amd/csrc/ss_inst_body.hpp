@@ -177,8 +177,39 @@ __global__ void __launch_bounds__(kBlock, SS_WAVES(R, NS, SS_MIN_WAVES_DOWN)) SS
   const int unit = blockIdx.x * kBlock + threadIdx.x;   // (column unit, pass), pass fastest
   const int cu = unit >> 1;
   if (cu >= L.ncu) return;
+#if defined(SS_DOWN_STAGGER)
+  // experiment: half of the waves start half a layer step late, so that the load phases of one half fall into the
+  // arithmetic phases of the other
+  if ((blockIdx.x >> 3) & 1) { for (int k = 0; k < SS_DOWN_STAGGER; ++k) __builtin_amdgcn_s_sleep(127); }
+#endif
   if (LW) column_down_lw<U, R, NS>(L, cu, unit & 1, nullptr);
   else column_down_sw<U, R, NS>(L, cu, unit & 1);
+}
+
+// downward flux sweep of the shortwave with both passes on one lane (ss_down_sw_both.hpp): lane = column unit
+template <bool U, int R, int NS>
+__global__ void __launch_bounds__(kBlock, 1) k_down_both(const Launch L) {
+  const int cu = blockIdx.x * kBlock + threadIdx.x;
+  if (cu >= L.ncu) return;
+#if defined(SS_DOWN_STAGGER)
+  if ((blockIdx.x >> 3) & 1) { for (int k = 0; k < SS_DOWN_STAGGER; ++k) __builtin_amdgcn_s_sleep(127); }
+#endif
+  if constexpr (sw_down_both(R * NS)) column_down_sw_both<U, R, NS>(L, cu);
+}
+
+// the downward kernel of a class: both passes on one lane where the vectors of both fit (shortwave, small orders),
+// else one lane per (column unit, pass)
+template <int NS>
+hipError_t launch_down(const Launch& L, hipStream_t stream) {
+  if constexpr (!SS_INST_LW && sw_down_both(SS_INST_NREG * NS)) {
+    hipLaunchKernelGGL((k_down_both<SS_INST_URBAN, SS_INST_NREG, NS>), dim3((unsigned)((L.ncu + kBlock - 1) / kBlock)),
+                       dim3(kBlock), 0, stream, L);
+  } else {
+    const unsigned gd = (unsigned)((2L * L.ncu + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((k_down<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gd), dim3(kBlock), 0,
+                       stream, L);
+  }
+  return hipGetLastError();
 }
 
 #define SS_TRY(call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
@@ -202,10 +233,7 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev, hipStream_t f
     SS_TRY(hipGetLastError());
     if (ev) SS_TRY(hipEventRecord(ev[1], stream));
     if (ev) SS_TRY(hipEventRecord(ev[2], stream));
-    const unsigned gd = (unsigned)((2L * L.ncu + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL((k_down<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gd), dim3(kBlock), 0,
-                       stream, L);
-    SS_TRY(hipGetLastError());
+    SS_TRY(launch_down<NS>(L, stream));
     if (ev) SS_TRY(hipEventRecord(ev[3], stream));
     return 0;
   }
@@ -269,10 +297,7 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev, hipStream_t f
                        dim3(((unsigned)L.ncu + upb - 1) / upb), dim3(kBlock16), 0, stream, L);
     SS_TRY(hipGetLastError());
   } else {
-    const unsigned gd = (unsigned)((2L * L.ncu + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL((k_down<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gd), dim3(kBlock), 0,
-                       stream, L);
-    SS_TRY(hipGetLastError());
+    SS_TRY(launch_down<NS>(L, stream));
   }
   if (ev) SS_TRY(hipEventRecord(ev[3], stream));
   return 0;

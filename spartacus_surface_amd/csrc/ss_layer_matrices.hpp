@@ -226,6 +226,55 @@ SS_HD void rec_store(double* rec, long stride, int off, const double* src) {
   }
 }
 
+// The records of ONE column unit in a scratch family (layer record, column record, input pack), addressed by
+// layer and element: on the device a buffer resource whose base is the wave's tile - uniform, four scalar
+// registers - plus ONE 32-bit byte offset per lane; the element offset of an access is a scalar operand.  With
+// flat 64-bit addresses a sweep that touches ~25 windows of 4 KB per layer keeps as many 64-bit pointers per lane
+// alive (and advances each of them every layer with a 64-bit add): ~50 VGPRs and ~200 VALU instructions per layer
+// of pure address arithmetic in the downward kernel.  Loads carry the non-temporal hint like rec_pair_load.
+struct RecView {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t r;
+  int voff0;        // byte offset of element 0 of layer 0 of this lane's unit from the resource base
+  int lay_bytes;    // bytes per layer slot of a tile
+  SS_HD RecView(const double* scratch, int maxlay, int nelem, int cu_abs) {
+    const int tile = cu_abs >> 6;
+    const int tile0 = __builtin_amdgcn_readfirstlane(tile);     // lanes ascend in cu: the smallest tile of the wave
+    lay_bytes = nelem * (int)kRecStride * 8;
+    const long tile_bytes = (long)maxlay * lay_bytes;
+    const char* base = reinterpret_cast<const char*>(scratch) + (long)tile0 * tile_bytes;
+    voff0 = (tile - tile0) * (int)tile_bytes + 16 * (cu_abs & 63);
+    const long range = 2 * tile_bytes;      // a wave spans at most two tiles (unaligned first unit of a chunk)
+    r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, range > 0x7fffffffL ? 0x7fffffff : (int)range, 0x00020000);
+  }
+  SS_HD RecPair pair(int jlay, int e) const {
+    typedef int ss_int4 __attribute__((ext_vector_type(4)));
+    const ss_int4 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff0 + jlay * lay_bytes, e * ((int)kRecStride * 8), 2);
+    const ss_double2 d = __builtin_bit_cast(ss_double2, t);
+    RecPair v;
+    v.x = d.x;
+    v.y = d.y;
+    return v;
+  }
+#else
+  const double* base;
+  long lay_stride;
+  SS_HD RecView(const double* scratch, int maxlay, int nelem, int cu_abs)
+      : base(scratch + rec_base(0, maxlay, nelem, cu_abs)), lay_stride((long)nelem * kRecStride) {}
+  SS_HD RecPair pair(int jlay, int e) const { return rec_pair_load(base + jlay * lay_stride + (long)e * kRecStride); }
+#endif
+  // NEL consecutive elements of layer jlay starting at the EVEN element "off"
+  template <int NEL>
+  SS_HD void load(int jlay, int off, double* dst) const {
+    SS_UNROLL_FULL
+    for (int k = 0; k < NEL; k += 2) {
+      const RecPair v = pair(jlay, off + k);
+      dst[k] = v.x;
+      if (k + 1 < NEL) dst[k + 1] = v.y;
+    }
+  }
+};
+
 // Writer of one scratch record (rec = scratch + rec_base(...))
 struct RecWriter {
   double* rec;
