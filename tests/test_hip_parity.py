@@ -20,12 +20,28 @@ from tests.conftest import golden_files
 pytestmark = pytest.mark.gpu
 
 # simple__test_noscat sets every single-scattering albedo to exactly zero, which
-# makes the reference's eigenvector route singular (G2 = X - X): its own fp64
-# output is then rounding noise for several variables (e.g. lw_norm%veg_abs is
-# 0.44 where exact arithmetic gives 0.084) and differs between any two fp64
-# evaluations at the per-cent level.  Parity there is a sanity check only:
-# variables the reference itself gets right to 1e-3 must agree to 5e-2.
+# makes the reference's eigenvector route singular (G2 = X - X) - in exact
+# arithmetic too: its binary128 evaluation AT zero jumps by 30 % from the limit
+# albedo -> 0+ (tests/golden/make_golden.py: SINGULAR_LIMIT), and its fp64 output
+# is rounding noise for several variables (lw_norm%veg_abs 0.44 where the limit
+# is 0.105).  Against the reference this case is a sanity check only (variables
+# the reference itself gets right to 1e-3 must agree to 5e-2); the tight check
+# is against that limit - binary128 at albedos of 1e-15, stored in the fixture
+# for every variable -, within LIMIT_TOL.
 REFERENCE_SINGULAR = {"simple__test_noscat": (1.0e-3, 5.0e-2)}
+LIMIT_TOL = 1.0e-5
+
+
+def check_against_limit(got, case, tol=LIMIT_TOL, collect=None, label=None):
+    """[(variable, error)] beyond tol against the stored limit of a reference-singular case."""
+    limit = case.get("ref_limit") or {}
+    assert limit, "fixture of a reference-singular case without its limit values"
+    # (variables that vanish in the limit - upwelling flux above a black ground without scattering - are rounding
+    # residue, 1e-14 here, 1e-12 in the reference: held to 1e-5 x 1e-6 of the scale of their flux object)
+    errs = fixture_io.rel_errors({k: got[k] for k in limit}, limit, zero_floor=1.0e-6)
+    if collect is not None and label is not None:
+        collect[label] = {k: {"err": e, "bar": tol, "ref_noise": 0.0, "ok": bool(e <= tol)} for k, e in errs.items()}
+    return sorted(((k, e) for k, e in errs.items() if not e <= tol), key=lambda kv: -kv[1])
 
 # Every comparison of this module leaves its full report here: per case and variable
 # {measured error, bar, the reference's own noise, both distances from binary128}.
@@ -50,8 +66,21 @@ def _dump_parity_report():
                         "widened_bars": len(over),
                         "max_err_where_bar_is_1e-5": max([r["err"] for r in rep.values()
                                                           if r["bar"] <= fixture_io.PARITY_TOL] or [0.0])}
+    # the honest headline: how many variables differ from the reference by more than the tolerance of north_star
+    # (the GPU path is more accurate than, not identical to, the reference: DESIGN.md section 2), and of those how
+    # many are farther from the binary128 evaluation than the reference itself is
+    allv = [r for label, rep in _REPORT.items() if not label.startswith("limit/") for r in rep.values()]
+    over_tol = [r for r in allv if r["err"] > fixture_io.PARITY_TOL]
+    farther = [r for r in over_tol if "gpu_vs_truth" in r and r["gpu_vs_truth"] > r["ref_vs_truth"]]
+    totals = {"cases": len(_REPORT), "variables": len(allv), "differ_from_reference_by_more_than_tol": len(over_tol),
+              "of_those_with_binary128_data": sum(1 for r in over_tol if "gpu_vs_truth" in r),
+              "of_those_farther_from_binary128_than_the_reference": len(farther),
+              "largest_difference_from_reference": max([r["err"] for r in allv] or [0.0])}
+    print("\nparity: %(differ_from_reference_by_more_than_tol)d of %(variables)d variables (%(cases)d cases) differ from "
+          "the reference by more than 1e-5, all within its measured fp64 noise; %(of_those_farther_from_binary128_than_the_reference)d "
+          "of them are farther from the binary128 evaluation than the reference is" % totals)
     with open(os.path.join(out_dir, "parity_report.json"), "w") as f:
-        json.dump({"tol": fixture_io.PARITY_TOL, "noise_factor": fixture_io.NOISE_FACTOR,
+        json.dump({"tol": fixture_io.PARITY_TOL, "noise_factor": fixture_io.NOISE_FACTOR, "totals": totals,
                    "summary": worst, "cases": _REPORT}, f, indent=1, sort_keys=True)
 
 
@@ -92,6 +121,9 @@ def test_golden_host_entry(path):
                                        noise_arr=None if singular else case["ref_noise_arr"],
                                        collect=_REPORT, label="golden/" + name)
     assert not bad, "outside the parity bar: %s" % bad[:5]
+    if singular:
+        far = check_against_limit(got, case, collect=_REPORT, label="limit/" + name)
+        assert not far, "farther than %g from the limit of the singular case: %s" % (LIMIT_TOL, far[:5])
 
 
 @pytest.mark.parametrize("name", ["simple__test_surfaces", "simple__test_overhang", "urban__2stream", "urban__4stream",

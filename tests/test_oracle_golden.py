@@ -9,9 +9,23 @@ import pytest
 from tests import fixture_io
 from tests.conftest import golden_files
 
-# The restatement keeps the reference's operation order, so it reproduces the
-# reference to rounding; 1e-11 leaves room for a different libm/compiler.
-TOL = 1.0e-11
+import numpy as np
+
+# The restatement keeps the reference's operation order and is compiled without floating-point contraction:
+# it reproduces the outputs of the compiled reference BIT FOR BIT on every fixture (gcc build against flang -O2
+# build, this image).  SPARTACUS_ORACLE_TOL=<rtol> relaxes that for another compiler / libm.
+TOL = float(os.environ.get("SPARTACUS_ORACLE_TOL", "0"))
+
+
+def assert_same(got, expected, what=""):
+    """bit-identical (NaN == NaN), or within SPARTACUS_ORACLE_TOL where that is set"""
+    for k, v in expected.items():
+        a, b = np.asarray(got[k]), np.asarray(v)
+        if TOL > 0.0:
+            assert np.allclose(a, b, rtol=TOL, atol=0.0, equal_nan=True), (what, k)
+        else:
+            same = (a == b) | (np.isnan(a) & np.isnan(b))
+            assert same.all(), "%s %s: %d of %d elements differ" % (what, k, int((~same).sum()), same.size)
 
 
 @pytest.mark.parametrize("path", golden_files(), ids=lambda p: os.path.basename(p)[:-4])
@@ -20,8 +34,7 @@ def test_oracle_matches_golden(path, checkers):
     out, _ = checkers.run_oracle(case["config"], case["canopy"], case["sw"], case["lw"],
                                  want_profiles=case["want_profiles"],
                                  do_simple_spectrum=case["do_simple_spectrum"])
-    err, where = fixture_io.max_rel_error(fixture_io.flatten_outputs(out), expected)
-    assert err <= TOL, "max rel error %.3e at %s" % (err, where)
+    assert_same(fixture_io.flatten_outputs(out), expected, os.path.basename(path)[:-4])
 
 
 def test_golden_set_is_complete():

@@ -1,7 +1,11 @@
 """Pin the CPU restatement against the REAL reference compiled from
 /root/reference (oracle/_ref): kernel-level (eigen decomposition, layer
 matrices) on seeded random matrices shaped like the solver's, and end to end on
-randomised columns.  Skipped where oracle/_ref is absent."""
+randomised columns.  Skipped where oracle/_ref is absent.
+
+The restatement follows the reference operation by operation and both are built without floating-point
+contraction, so every comparison here is BIT FOR BIT (measured: zero differing elements in the eigen
+decompositions, the layer matrices of all orders and the outputs of all 78 cases)."""
 import numpy as np
 import pytest
 
@@ -31,8 +35,8 @@ def test_eigen_decomposition(n, checkers):
     a = np.einsum("mij,mjk->mik", g1 - g2, g1 + g2)
     v_ref, x_ref = checkers.eigen_decomposition_real(a, "ref")
     v_or, x_or = checkers.eigen_decomposition_real(a, "oracle")
-    assert np.allclose(v_ref, v_or, rtol=1e-13, atol=0)
-    assert np.allclose(x_ref, x_or, rtol=1e-12, atol=1e-14)
+    assert np.array_equal(v_ref, v_or)
+    assert np.array_equal(x_ref, x_or)
 
 
 def test_eigen_decomposition_isolated_and_degenerate(checkers):
@@ -56,7 +60,7 @@ def test_calc_matrices_sw_eig(n, d, checkers):
     r = checkers.calc_matrices_sw_eig(2.5, 0.6, g0, g1, g2, g3, "ref")
     o = checkers.calc_matrices_sw_eig(2.5, 0.6, g0, g1, g2, g3, "oracle")
     for k in r:
-        assert np.allclose(r[k], o[k], rtol=1e-11, atol=1e-14), k
+        assert np.array_equal(r[k], o[k]), k
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 6, 12])
@@ -67,7 +71,7 @@ def test_calc_matrices_lw_eig(n, checkers):
     r = checkers.calc_matrices_lw_eig(3.0, g1, g2, b, "ref")
     o = checkers.calc_matrices_lw_eig(3.0, g1, g2, b, "oracle")
     for k in r:
-        assert np.allclose(r[k], o[k], rtol=1e-11, atol=1e-14), k
+        assert np.array_equal(r[k], o[k]), k
 
 
 def test_known_answer_test_sw(checkers):
@@ -84,7 +88,7 @@ def test_known_answer_test_sw(checkers):
     r = checkers.calc_matrices_sw_eig(float(f(2.0)), float(f(0.25882)), g0, g1, g2, g3, "ref")
     o = checkers.calc_matrices_sw_eig(float(f(2.0)), float(f(0.25882)), g0, g1, g2, g3, "oracle")
     for k in r:
-        assert np.allclose(r[k], o[k], rtol=1e-12, atol=1e-15), k
+        assert np.array_equal(r[k], o[k]), k
 
 
 def test_legendre_gauss_tables(checkers):
@@ -98,7 +102,7 @@ def test_legendre_gauss_tables(checkers):
         assert abs(ref.vadjustment2 - lg.vadjustment2) <= 1e-15 * abs(ref.vadjustment2)
 
 
-def test_all_reference_cases_bit_close(checkers):
+def test_all_reference_cases_bit_identical(checkers):
     """Every run of the reference's `make test`, regenerated from its inputs."""
     from tests import cases, fixture_io
     if not cases.have_reference_inputs():
@@ -111,6 +115,6 @@ def test_all_reference_cases_bit_close(checkers):
                                 do_simple_spectrum=c["do_simple_spectrum"])
         o, _ = checkers.run_oracle(c["config"], c["canopy"], c["sw"], c["lw"],
                                    do_simple_spectrum=c["do_simple_spectrum"])
-        err, where = fixture_io.max_rel_error(fixture_io.flatten_outputs(o),
-                                              fixture_io.flatten_outputs(r))
-        assert err <= 1e-11, (name, err, where)
+        of, rf = fixture_io.flatten_outputs(o), fixture_io.flatten_outputs(r)
+        for k in rf:
+            assert np.array_equal(np.asarray(of[k]), np.asarray(rf[k]), equal_nan=True), (name, k)
