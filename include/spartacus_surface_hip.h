@@ -339,6 +339,43 @@ int ss_plan_destroy(ss_plan *plan);
 int ss_host_entry_plan_creations(int64_t *count);
 
 /* --------------------------------------------------------------------------
+ * Several GPUs of one node from ONE process (scope row e).  The reference's only
+ * parallel construct is one process looping over column blocks
+ * (driver/spartacus_surface_driver.F90:203-234), so the fan-out lives inside the
+ * library: nothing of the host model changes, no MPI, no second process.
+ *
+ * ss_set_devices: large calls of spartacus_radsurf_hip (more than 2048 columns) cut
+ * [istartcol, iendcol] into one contiguous shard per listed device, balanced by
+ * layer count; one host thread per shard drives its device's chunk pipeline, and
+ * every device moves its own slices of the caller's arrays - no result crosses
+ * from one device to another, no gather.  ndevices = 0 returns to the calling
+ * thread's current device.  A device may be listed more than once (several shards on
+ * one GPU).  Without a call the list is read once from the environment:
+ * SPARTACUS_DEVICES = "all" | <count> | <d0>,<d1>,...
+ *
+ * ss_plan_create_multi: the device-resident form - one plan per shard, each on its
+ * device, over disjoint column ranges of the SAME caller objects.  solve queues the
+ * work of every part and returns; download lets every part write its slices of the
+ * full-size objects.  ss_multi_plan_part hands out the parts (plan, device, column
+ * range) for every other plan entry (upload, scale_and_sum, device pointers ...).
+ * -------------------------------------------------------------------------- */
+int ss_set_devices(const int32_t *devices, int32_t ndevices);
+int ss_get_devices(int32_t *devices, int32_t capacity, int32_t *ndevices);
+typedef struct ss_multi_plan ss_multi_plan;
+int ss_plan_create_multi(ss_multi_plan **mplan, const ss_config *config, const ss_canopy *canopy,
+                         const ss_sw_spectral *sw, const ss_lw_spectral *lw, int32_t istartcol,
+                         int32_t iendcol, int32_t want_profiles, const int32_t *devices,
+                         int32_t ndevices);
+int ss_multi_plan_count(ss_multi_plan *mplan, int32_t *nparts);
+int ss_multi_plan_part(ss_multi_plan *mplan, int32_t k, ss_plan **plan, int32_t *device,
+                       int32_t *istartcol, int32_t *iendcol);
+int ss_multi_plan_solve(ss_multi_plan *mplan);
+int ss_multi_plan_synchronize(ss_multi_plan *mplan);
+int ss_multi_plan_download(ss_multi_plan *mplan, ss_bc_out *bc_out, ss_flux *sw_norm_dir,
+                           ss_flux *sw_norm_diff, ss_flux *lw_internal, ss_flux *lw_norm);
+int ss_multi_plan_destroy(ss_multi_plan *mplan);
+
+/* --------------------------------------------------------------------------
  * Kernel-level entry points: the layer-matrix units of the hot path on their
  * own, with the argument lists of radtool's routines (stacks of nmat independent
  * problems, HOST arrays in Fortran layout x(nmat, i, j) -> x[m + nmat*(i + n*j)]).

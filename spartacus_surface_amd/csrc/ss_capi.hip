@@ -13,6 +13,7 @@
 #include <mutex>
 #include <shared_mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/spartacus_surface_hip.h"
@@ -143,7 +144,18 @@ struct PinRegistry {
     // partial overlap with an entry: refuse (never unregister what someone else owns and may be using)
     auto it = ranges.lower_bound(a);
     if (end || (it != ranges.end() && it->first < b)) return false;
-    if (hipHostRegister(const_cast<void*>(p), n, hipHostRegisterDefault) != hipSuccess) {
+    // memory the caller page-locked itself (hipHostRegister / hipHostMalloc outside this library): not ours - a
+    // second registration of the same base would succeed, and our release would then take the caller's lock (or
+    // the device pointer it mapped) away.  It moves by DMA as it is; nothing is recorded.
+    {
+      hipPointerAttribute_t attr;
+      if (hipPointerGetAttributes(&attr, p) == hipSuccess) {
+        if (attr.type == hipMemoryTypeHost) return true;
+      } else {
+        (void)hipGetLastError();            // plain pageable memory: "invalid value"
+      }
+    }
+    if (hipHostRegister(const_cast<void*>(p), n, hipHostRegisterPortable) != hipSuccess) {   // every device of the call
       (void)hipGetLastError();              // stays pageable: slower, still correct
       return false;
     }
@@ -152,14 +164,18 @@ struct PinRegistry {
     return true;
   }
   // caller: nothing queued may still use the ranges (the host entry synchronises first)
-  void release(bool call_owned_only, const void* only_base = nullptr) {
+  // returns the number of registrations dropped
+  int release(bool call_owned_only, const void* only_base = nullptr) {
     std::lock_guard<std::mutex> lock(mu);
+    int dropped = 0;
     for (auto it = ranges.begin(); it != ranges.end();) {
       if ((call_owned_only && !it->second.call_owned) || (only_base && it->first != (const char*)only_base)) { ++it; continue; }
       if (hipHostUnregister(const_cast<char*>(it->first)) != hipSuccess) (void)hipGetLastError();
       bytes -= it->second.bytes;
       it = ranges.erase(it);
+      ++dropped;
     }
+    return dropped;
   }
   size_t pinned_bytes() const { std::lock_guard<std::mutex> lock(mu); return bytes; }
 };
@@ -587,7 +603,6 @@ struct HostEntry {
   }
   ss_config cfg;
   int profiles = -1, device = -1;
-  std::atomic<long> creations{0};   // sub-plans built so far, small-call slots included (tests: block calls must not re-create)
 
   void streams() {
     if (!up) HIP_CHECK_THROW(hipStreamCreateWithFlags(&up, hipStreamNonBlocking));
@@ -605,7 +620,51 @@ struct HostEntry {
     device = -1;
   }
 };
-HostEntry g_host;           // deliberately never destroyed at process exit (HIP may be gone)
+// One HostEntry per shard of a large call: shard 0 is the calling thread's current device (the only one unless
+// devices were configured, ss_set_devices / SPARTACUS_DEVICES); deliberately never destroyed at process exit
+// (HIP may be gone).  Guarded by g_device_mutex (large calls are exclusive).
+std::vector<HostEntry*>& g_hosts = *new std::vector<HostEntry*>();
+HostEntry& host_entry(size_t shard) {
+  while (g_hosts.size() <= shard) g_hosts.push_back(new HostEntry);
+  return *g_hosts[shard];
+}
+std::atomic<long> g_plan_creations{0};   // sub-plans built by the host entry so far, small-call slots included
+
+// Devices of the host entry (row e of the scope: columns shard over the GPUs of a node; the reference's only
+// parallel construct is one process looping over column blocks, driver/spartacus_surface_driver.F90:203-234, so
+// the fan-out lives HERE, inside the one call its untouched driver makes).  Empty = the calling thread's current
+// device.  A device may be listed more than once (several shards on one GPU: how the one-GPU test box
+// exercises the path).  Set by ss_set_devices or, if that was never called, read once from SPARTACUS_DEVICES
+// ("all", a count, or a comma-separated list).
+std::vector<int> g_devices;
+bool g_devices_set = false;
+void devices_from_env() {
+  if (g_devices_set) return;
+  g_devices_set = true;
+  const char* e = std::getenv("SPARTACUS_DEVICES");
+  if (!e || !*e) return;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  const std::string v(e);
+  if (v == "all") {
+    for (int d = 0; d < n; ++d) g_devices.push_back(d);
+  } else if (v.find(',') == std::string::npos) {
+    const int k = std::atoi(v.c_str());
+    for (int d = 0; d < k && d < n; ++d) g_devices.push_back(d);
+  } else {
+    size_t a = 0;
+    while (a <= v.size()) {
+      const size_t b = v.find(',', a);
+      const std::string tok = v.substr(a, b == std::string::npos ? std::string::npos : b - a);
+      if (!tok.empty()) {
+        const int d = std::atoi(tok.c_str());
+        if (d >= 0 && d < n) g_devices.push_back(d);
+      }
+      if (b == std::string::npos) break;
+      a = b + 1;
+    }
+  }
+}
 
 
 // SPARTACUS_PIN_HOST=1: page-lock the slices of the caller's arrays this call touches - columns
@@ -898,7 +957,7 @@ int small_call(SmallSlot& sl, const ss_config* config, const ss_canopy* canopy, 
   int r;
   if (fresh) {
     p->pipes_cap = 1;          // everything of a slot on its one stream, in order: no events between streams
-    ++g_host.creations;
+    ++g_plan_creations;
     r = p->create(config, &v.can, sw ? &v.sw : nullptr, lw ? &v.lw : nullptr, 1, c_end - c_begin, profiles);
   } else {
     r = p->reset(&v.can, sw ? &v.sw : nullptr, lw ? &v.lw : nullptr, 1, c_end - c_begin, false);
@@ -924,6 +983,182 @@ int small_call(SmallSlot& sl, const ss_config* config, const ss_canopy* canopy, 
   return SS_OK;
 }
 
+// One shard of a large call - columns [c_begin, c_end) of the caller's arrays - through the chunk pipeline of the
+// HostEntry H on the calling thread's current device (= "device").  The caller's arrays are page-locked (or not)
+// by the entry before the shards start; a shard never returns while its device may still touch them.
+int large_call_shard(HostEntry& H, int device, const ss_config* config, const ss_canopy* canopy, const ss_sw_spectral* sw,
+                     const ss_lw_spectral* lw, ss_bc_out* bc_out, int c_begin, int c_end, ss_flux* const* fl,
+                     int profiles) {
+  auto body = [&]() -> int {
+    const bool nocache = std::getenv("SPARTACUS_NO_PLAN_CACHE") != nullptr;
+    if (H.slot[0] && (nocache || H.profiles != profiles || H.device != device
+                           || std::memcmp(&H.cfg, config, sizeof(ss_config)) != 0))
+      H.drop();
+    H.cfg = *config;
+    H.profiles = profiles;
+    H.device = device;
+
+    long call_l0 = 0, call_l1 = 0;
+    layer_range(canopy, c_begin, c_end, &call_l0, &call_l1);
+    // are the caller's (large) arrays page-locked - by the lines above or by ss_host_pin?
+    const bool pinned = canopy->dz && call_l1 > call_l0
+                        && g_pins.covered(canopy->dz + call_l0, sizeof(double) * (size_t)(call_l1 - call_l0));
+    const bool always_seed = std::getenv("SPARTACUS_ALWAYS_SEED") != nullptr;
+    // per-column outputs: call-level device arrays, one download per member at the end
+    const std::vector<ColumnOutput> col_out = column_outputs(config, profiles, bc_out, fl);
+    std::vector<double*> col_dev(col_out.size());
+    for (size_t i = 0; i < col_out.size(); ++i)
+      col_dev[i] = H.arena_get(col_out[i].name, (size_t)col_out[i].width * (size_t)(c_end - c_begin));
+    // per-layer outputs: call-level device arrays too - the sub-plans write their chunk's layer range of them,
+    // and they come home in copies that do NOT follow the chunking: one per member for every group of chunks
+    // (the download engine starts ~30 us late on every copy; 34 members x 7 chunks of such gaps were a third
+    // of a pinned 200 000-column call)
+    const std::vector<ColumnOutput> lay_out = layer_outputs(config, profiles, fl);
+    std::vector<double*> lay_dev(lay_out.size());
+    for (size_t i = 0; i < lay_out.size(); ++i)
+      lay_dev[i] = H.arena_get(lay_out[i].name, (size_t)lay_out[i].width * (size_t)std::max<long>(1, call_l1 - call_l0));
+    long col_home = c_begin;       // columns [c_begin, col_home): per-column members on their way to the host
+    constexpr int NS = HostEntry::kSlots;
+    ChunkView views[NS];
+    bool inflight[NS] = {};     // kernels of the slot's chunk may still be running
+    int r = SS_OK;
+    auto fail = [&](HipPlan* p, int code) {
+      if (p) g_last_error = p->error;
+      return code;              // leave() synchronises, then drops the sub-plans
+    };
+    auto fl_of = [](ChunkView& v, int k) { return v.have_fl[k] ? &v.fl[k] : nullptr; };
+    // SPARTACUS_HOST_TIMING=1: wall-clock milliseconds of the host thread per chunk and phase (stderr)
+    const bool timing = std::getenv("SPARTACUS_HOST_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now();
+    int k = 0, chunk = 0;
+    for (int c0 = c_begin; c0 < c_end; c0 += chunk, ++k) {
+      chunk = next_chunk_columns(c_end - c_begin, chunk, pinned);
+      const int c1 = std::min(c_end, c0 + chunk), s = k % NS;
+      const double ta = now();
+      HipPlan*& p = H.slot[s];
+      if (inflight[s]) {          // the chunk NS back used this slot: its kernels must be done before its inputs are replaced
+        p->be.sync();
+        inflight[s] = false;
+      }
+      const double tw = now();
+      ChunkView& v = views[s];
+      make_view(canopy, sw, lw, bc_out, fl, config->nsw, config->nlw, c0, c1, v);
+      const bool fresh = !p;
+      if (fresh) p = new HipPlan;
+      p->unbind_externals();      // bindings of an earlier call (other members, other sizes) end here
+      for (size_t i = 0; i < col_out.size(); ++i)
+        p->bind_external(col_out[i].name, col_dev[i] + (size_t)col_out[i].width * (size_t)(c0 - c_begin),
+                         (size_t)col_out[i].width * (size_t)(c1 - c0));
+      long chunk_l0, chunk_l1;
+      layer_range(canopy, c0, c1, &chunk_l0, &chunk_l1);
+      if (chunk_l1 <= chunk_l0) chunk_l0 = chunk_l1 = call_l0;
+      for (size_t i = 0; i < lay_out.size(); ++i)
+        p->bind_external(lay_out[i].name, lay_dev[i] + (size_t)lay_out[i].width * (size_t)(chunk_l0 - call_l0),
+                         (size_t)lay_out[i].width * (size_t)std::max<long>(1, chunk_l1 - chunk_l0));
+      if (fresh) {
+        // one stream per sub-plan: the two sub-plans then sit on two hardware queues of their own, and
+        // what this entry has to hide is PCIe time, not the (shorter) kernel time
+        p->pipes_cap = 1;
+        ++g_plan_creations;
+        H.streams();
+        // (a second download stream taken in turn by successive chunks, to fill the start-up gaps
+        // between a chunk's ~60 copies, was measured slower: 1.04e7 -> 0.84e7 columns/s - more
+        // streams than hardware queues)
+        if (!std::getenv("SPARTACUS_HOST_ONE_STREAM")) p->be.set_transfer_streams(H.up, H.down);
+        r = p->create(config, &v.can, sw ? &v.sw : nullptr, lw ? &v.lw : nullptr, 1, c1 - c0, profiles);
+      } else {
+        // no wait: the copies of this chunk stay queued in front of its kernels (the caller's
+        // arrays are ours until this entry returns); page-locked arrays then move by DMA while
+        // the host thread goes on
+        r = p->reset(&v.can, sw ? &v.sw : nullptr, lw ? &v.lw : nullptr, 1, c1 - c0, false);
+      }
+      if (r) return fail(p, r);
+      const double tb = now();
+      p->upload_outputs(&v.bc, fl_of(v, 0), fl_of(v, 1), fl_of(v, 2), fl_of(v, 3),
+                        always_seed ? (int)HipPlan::SEED_ALL : p->seed_needed());
+      const double tc = now();
+      r = p->solve();
+      if (r) return fail(p, r);
+      const double td = now();
+      inflight[s] = true;
+      // The per-layer results of this chunk come home behind its kernels: its OWN layer range (nothing is assumed
+      // about the order of the columns' layers in the packed arrays), gated on its own stream.  (Fewer, larger
+      // copies - every second / third chunk - were measured and are not faster: the transfer is bound by its bytes.)
+      if (chunk_l1 > chunk_l0) {
+        hipStream_t ds = p->be.gate_downloads();      // the download stream waits for everything queued on this plan's stream
+        for (size_t i = 0; i < lay_out.size(); ++i) {
+          const size_t w = (size_t)lay_out[i].width;
+          HipBackend::copy_async(lay_out[i].host + w * (size_t)chunk_l0, lay_dev[i] + w * (size_t)(chunk_l0 - call_l0),
+                                 w * (size_t)(chunk_l1 - chunk_l0) * sizeof(double), hipMemcpyDeviceToHost, ds);
+        }
+      }
+      if (timing)
+        std::fprintf(stderr, "host entry chunk %d (%d cols): wait for slot %.2f, view+upload %.2f, seed %.2f, solve queued %.2f, download queued %.2f ms\n",
+                     k, c1 - c0, tw - ta, tb - tw, tc - tb, td - tc, now() - td);
+    }
+    for (int s = 0; s < NS; ++s) {
+      if (!inflight[s]) continue;
+      const double te = now();
+      H.slot[s]->be.sync();
+      if (timing) std::fprintf(stderr, "host entry: slot %d done after %.2f ms\n", s, now() - te);
+    }
+    // every kernel of the call has completed: the per-column outputs, one copy per member.  (Measured, 200 000
+    // columns: sending them with every chunk - 27 more ~1 MB copies per download point - 17.1 -> 20.2 ms; once
+    // at two thirds of the call and once at the end 18.7 ms; all at the end 17.3 ms.  Likewise the per-layer
+    // members: with every chunk 17.3, every second 17.5, every third 18.1, all at the end 22.3 ms: the transfer
+    // is bound by the bytes, ~45 GB/s down while ~30 GB/s go up, not by the number of copies.)
+    {
+      const double te = now();
+      hipStream_t ds = H.down ? H.down : nullptr;
+      for (size_t i = 0; i < col_out.size(); ++i) {
+        const size_t w = (size_t)col_out[i].width;
+        HipBackend::copy_async(col_out[i].host + w * (size_t)col_home, col_dev[i] + w * (size_t)(col_home - c_begin),
+                               w * (size_t)(c_end - col_home) * sizeof(double), hipMemcpyDeviceToHost, ds);
+      }
+      HIP_CHECK_THROW(hipStreamSynchronize(ds));
+      if (timing) std::fprintf(stderr, "host entry: %zu per-column members home after %.2f ms\n", col_out.size(), now() - te);
+    }
+    if (timing) std::fprintf(stderr, "host entry total %.2f ms\n", now() - t_start);
+    if (nocache) H.drop();
+    return r;
+  };
+  auto leave = [&](bool failed) {
+    if (failed) {
+      (void)hipDeviceSynchronize();
+      (void)hipGetLastError();
+      H.drop();            // sub-plans with half-done state (pending downloads, bindings) are not reused
+    }
+  };
+  return guarded([&]() -> int {
+    int r;
+    try {
+      r = body();
+    } catch (...) {
+      leave(true);
+      throw;
+    }
+    leave(r != SS_OK);
+    return r;
+  });
+}
+
+// Contiguous column shards of [c_begin, c_end) balanced by the number of layers (+ 1 per column: tiles without
+// layers still cost an upload and a kernel lane); shard k = [cut[k], cut[k + 1])
+std::vector<int> shard_cuts(const ss_canopy* can, int c_begin, int c_end, int nshards) {
+  std::vector<int> cut(nshards + 1, c_end);
+  cut[0] = c_begin;
+  double total = 0.0;
+  for (int j = c_begin; j < c_end; ++j) total += 1.0 + std::max(0, can->nlay[j]);
+  double acc = 0.0;
+  int k = 1;
+  for (int j = c_begin; j < c_end && k < nshards; ++j) {
+    acc += 1.0 + std::max(0, can->nlay[j]);
+    while (k < nshards && acc >= total * k / nshards) cut[k++] = j + 1;
+  }
+  return cut;
+}
+
 }  // namespace
 
 extern "C" {
@@ -947,7 +1182,37 @@ int ss_set_device(int32_t device) {
 }
 
 const char* ss_last_error(void) { return g_last_error.c_str(); }
-const char* ss_version(void) { return "spartacus_surface_hip 0.2 (gfx950)"; }
+const char* ss_version(void) { return "spartacus_surface_hip 0.3 (gfx950)"; }
+
+// Devices of the host entry: large calls of spartacus_radsurf_hip cut [istartcol, iendcol] into one contiguous
+// shard per listed device (balanced by layer count), one host thread per shard.  ndevices = 0: back to the
+// calling thread's current device.  A device may be listed more than once.
+int ss_set_devices(const int32_t* devices, int32_t ndevices) {
+  int rc = device_ready();
+  if (rc) return rc;
+  if (ndevices < 0 || (ndevices > 0 && !devices)) return SS_ERR_BAD_ARGUMENT;
+  int n = 0;
+  if (!hip_ok(hipGetDeviceCount(&n), "hipGetDeviceCount")) return SS_ERR_HIP;
+  for (int k = 0; k < ndevices; ++k)
+    if (devices[k] < 0 || devices[k] >= n) {
+      g_last_error = "ss_set_devices: no such device";
+      return SS_ERR_BAD_ARGUMENT;
+    }
+  std::unique_lock<std::shared_mutex> entry_lock(g_entry_mutex);
+  std::lock_guard<std::mutex> lock(g_device_mutex);
+  g_devices.assign(devices, devices + ndevices);
+  g_devices_set = true;
+  return SS_OK;
+}
+
+int ss_get_devices(int32_t* devices, int32_t capacity, int32_t* ndevices) {
+  if (!ndevices) return SS_ERR_BAD_ARGUMENT;
+  std::lock_guard<std::mutex> lock(g_device_mutex);
+  devices_from_env();
+  *ndevices = (int32_t)g_devices.size();
+  for (int k = 0; devices && k < capacity && k < (int)g_devices.size(); ++k) devices[k] = g_devices[k];
+  return SS_OK;
+}
 
 int ss_plan_create(ss_plan** plan, const ss_config* config, const ss_canopy* canopy,
                    const ss_sw_spectral* sw, const ss_lw_spectral* lw, int32_t istartcol,
@@ -1103,6 +1368,104 @@ int ss_plan_destroy(ss_plan* plan) {
   });
 }
 
+// ---- one column set on several devices: a plan per contiguous shard ----
+struct ss_multi_plan {
+  struct Part { ss_plan* plan; int device, istartcol, iendcol; };
+  std::vector<Part> parts;
+};
+
+int ss_plan_create_multi(ss_multi_plan** mplan, const ss_config* config, const ss_canopy* canopy,
+                         const ss_sw_spectral* sw, const ss_lw_spectral* lw, int32_t istartcol, int32_t iendcol,
+                         int32_t want_profiles, const int32_t* devices, int32_t ndevices) {
+  if (!mplan || !config || !canopy || ndevices < 1 || !devices) return SS_ERR_BAD_ARGUMENT;
+  int rc = device_ready();
+  if (rc) return rc;
+  if (istartcol < 1 || iendcol > canopy->ncol || iendcol < istartcol) {
+    g_last_error = "column range out of bounds";
+    return SS_ERR_BAD_ARGUMENT;
+  }
+  int prev = 0;
+  if (!hip_ok(hipGetDevice(&prev), "hipGetDevice")) return SS_ERR_HIP;
+  const int nparts = std::min<int>(ndevices, std::max(1, (iendcol - istartcol + 1) / 64));
+  const std::vector<int> cut = shard_cuts(canopy, istartcol - 1, iendcol, nparts);
+  ss_multi_plan* mp = new ss_multi_plan();
+  int r = SS_OK;
+  for (int k = 0; k < nparts && r == SS_OK; ++k) {
+    if (cut[k + 1] <= cut[k]) continue;
+    if (!hip_ok(hipSetDevice(devices[k]), "hipSetDevice")) { r = SS_ERR_HIP; break; }
+    ss_plan* p = nullptr;
+    r = ss_plan_create(&p, config, canopy, sw, lw, cut[k] + 1, cut[k + 1], want_profiles);
+    if (r == SS_OK) mp->parts.push_back({p, devices[k], cut[k] + 1, cut[k + 1]});
+  }
+  (void)hipSetDevice(prev);
+  if (r != SS_OK) {
+    for (auto& q : mp->parts) ss_plan_destroy(q.plan);
+    delete mp;
+    return r;
+  }
+  *mplan = mp;
+  return SS_OK;
+}
+
+int ss_multi_plan_count(ss_multi_plan* mplan, int32_t* nparts) {
+  if (!mplan || !nparts) return SS_ERR_BAD_ARGUMENT;
+  *nparts = (int32_t)mplan->parts.size();
+  return SS_OK;
+}
+
+int ss_multi_plan_part(ss_multi_plan* mplan, int32_t k, ss_plan** plan, int32_t* device, int32_t* istartcol,
+                       int32_t* iendcol) {
+  if (!mplan || k < 0 || k >= (int32_t)mplan->parts.size()) return SS_ERR_BAD_ARGUMENT;
+  const auto& q = mplan->parts[k];
+  if (plan) *plan = q.plan;
+  if (device) *device = q.device;
+  if (istartcol) *istartcol = q.istartcol;
+  if (iendcol) *iendcol = q.iendcol;
+  return SS_OK;
+}
+
+// queues the solve of every part on its device and returns (like ss_plan_solve)
+int ss_multi_plan_solve(ss_multi_plan* mplan) {
+  if (!mplan) return SS_ERR_BAD_ARGUMENT;
+  for (auto& q : mplan->parts) {
+    const int r = ss_plan_solve(q.plan);
+    if (r != SS_OK) return r;
+  }
+  return SS_OK;
+}
+
+int ss_multi_plan_synchronize(ss_multi_plan* mplan) {
+  if (!mplan) return SS_ERR_BAD_ARGUMENT;
+  int rc = SS_OK;
+  for (auto& q : mplan->parts) {
+    const int r = ss_plan_synchronize(q.plan);
+    if (r != SS_OK && rc == SS_OK) rc = r;
+  }
+  return rc;
+}
+
+// every part writes its own column / layer slices of the caller's (full-size) objects
+int ss_multi_plan_download(ss_multi_plan* mplan, ss_bc_out* bc_out, ss_flux* sw_norm_dir, ss_flux* sw_norm_diff,
+                           ss_flux* lw_internal, ss_flux* lw_norm) {
+  if (!mplan) return SS_ERR_BAD_ARGUMENT;
+  for (auto& q : mplan->parts) {
+    const int r = ss_plan_download(q.plan, bc_out, sw_norm_dir, sw_norm_diff, lw_internal, lw_norm);
+    if (r != SS_OK) return r;
+  }
+  return SS_OK;
+}
+
+int ss_multi_plan_destroy(ss_multi_plan* mplan) {
+  if (!mplan) return SS_OK;
+  int rc = SS_OK;
+  for (auto& q : mplan->parts) {
+    const int r = ss_plan_destroy(q.plan);
+    if (r != SS_OK && rc == SS_OK) rc = r;
+  }
+  delete mplan;
+  return rc;
+}
+
 int ss_host_pin(const void* ptr, int64_t bytes) {
   if (!ptr || bytes <= 0) return SS_ERR_BAD_ARGUMENT;
   int rc = device_ready();
@@ -1119,15 +1482,26 @@ int ss_host_pin(const void* ptr, int64_t bytes) {
 // device first (a queued copy must not lose its registration).
 int ss_host_unpin(const void* ptr) {
   if (!ptr) return SS_ERR_BAD_ARGUMENT;
+  int rc = device_ready();
+  if (rc) return rc;
+  // no host-entry call - small ones included, which only share this lock - may be in flight while a
+  // registration is dropped: a DMA queued from the range would lose it
+  std::unique_lock<std::shared_mutex> entry_lock(g_entry_mutex);
   std::lock_guard<std::mutex> lock(g_device_mutex);
-  (void)hipDeviceSynchronize();
-  g_pins.release(false, ptr);
+  if (!hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize")) return SS_ERR_HIP;
+  if (g_pins.release(false, ptr) == 0) {
+    g_last_error = "ss_host_unpin: not the base of a registration made by ss_host_pin";
+    return SS_ERR_BAD_ARGUMENT;
+  }
   return SS_OK;
 }
 
 int ss_host_unpin_all(void) {
+  int rc = device_ready();
+  if (rc) return rc;
+  std::unique_lock<std::shared_mutex> entry_lock(g_entry_mutex);
   std::lock_guard<std::mutex> lock(g_device_mutex);
-  (void)hipDeviceSynchronize();
+  if (!hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize")) return SS_ERR_HIP;
   g_pins.release(false);
   return SS_OK;
 }
@@ -1142,7 +1516,7 @@ int ss_host_pinned_bytes(int64_t* bytes) {
 int ss_host_entry_plan_creations(int64_t* count) {
   if (!count) return SS_ERR_BAD_ARGUMENT;
   std::lock_guard<std::mutex> lock(g_device_mutex);
-  *count = g_host.creations;
+  *count = g_plan_creations;
   return SS_OK;
 }
 
@@ -1177,11 +1551,14 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
             // a free slot (one that already holds a plan first: a sequential caller stays on one slot), else queue up
             SmallSlot* sl = nullptr;
             std::unique_lock<std::mutex> own;
+            // (a slot's members are only read under its mutex: another thread may be building its plan)
             for (int pass = 0; pass < 2 && !sl; ++pass)
               for (int i = 0; i < SmallPool::kSlots && !sl; ++i) {
-                if (pass == 0 && !g_small.slot[i].plan) continue;
                 std::unique_lock<std::mutex> t(g_small.slot[i].mu, std::try_to_lock);
-                if (t.owns_lock()) { sl = &g_small.slot[i]; own = std::move(t); }
+                if (!t.owns_lock()) continue;
+                if (pass == 0 && !g_small.slot[i].plan) continue;      // (t unlocks)
+                sl = &g_small.slot[i];
+                own = std::move(t);
               }
             if (!sl) {
               sl = &g_small.slot[g_small.next++ % SmallPool::kSlots];
@@ -1211,198 +1588,80 @@ int spartacus_radsurf_hip(const ss_config* config, const ss_canopy* canopy, cons
       }
     }
   }
-  // ... large calls have the device to themselves.
+  // ... large calls have the device(s) to themselves.
   std::unique_lock<std::shared_mutex> entry_lock(g_entry_mutex);
   std::lock_guard<std::mutex> lock(g_device_mutex);
+  const int profiles = ((sw_norm_dir && sw_norm_dir->flux_dn_layer_top)
+                        || (lw_internal && lw_internal->flux_dn_layer_top)) ? 1 : 0;
+  ss_flux* fl[4] = {config->do_sw ? sw_norm_dir : nullptr, config->do_sw ? sw_norm_diff : nullptr,
+                    config->do_lw ? lw_internal : nullptr, config->do_lw ? lw_norm : nullptr};
+  const int c_begin = istartcol - 1, c_end = iendcol;
+  int device = 0;
+  if (!hip_ok(hipGetDevice(&device), "hipGetDevice")) return SS_ERR_HIP;
+  devices_from_env();
+  // shards: one per configured device (not more than there are blocks of 64 columns), else the current device
+  std::vector<int> devs = g_devices;
+  if (devs.empty()) devs.push_back(device);
+  // (SPARTACUS_SHARD_MIN_COLUMNS: smallest shard worth a host thread and a pipeline of its own, default 64 columns;
+  // the tests lower it to send the reference's small inputs through the fan-out)
+  const char* sme = std::getenv("SPARTACUS_SHARD_MIN_COLUMNS");
+  const int shard_min = std::max(1, sme ? std::atoi(sme) : 64);
+  const int max_shards = std::max(1, (c_end - c_begin) / shard_min);
+  if ((int)devs.size() > max_shards) devs.resize(max_shards);
+  // SPARTACUS_PIN_HOST: registrations owned by this call (PinRegistry), made once for all shards and released
+  // when every shard has returned.  Call-owned locks are the DEFAULT for calls of 32768 columns and more
+  // (measured on this box: locking and releasing ~1 GB per call costs ~1 ms from the second call on, the pipeline
+  // it enables takes 27 -> 17 ms off a 200 000-column call); SPARTACUS_PIN_HOST=1 lowers the threshold to
+  // SPARTACUS_PIN_HOST_MIN_COLUMNS (default 4096), SPARTACUS_PIN_HOST=0 switches locking off.
   bool pins_made = false;
-  // Whatever happens inside, the entry does not return while the device may still touch the caller's
-  // arrays (asynchronous copies into page-locked memory) and it leaves no call-owned registration behind.
-  auto leave = [&](bool failed) {
-    if (failed) {
-      (void)hipDeviceSynchronize();
-      (void)hipGetLastError();
-      g_host.drop();            // sub-plans with half-done state (pending downloads, bindings) are not reused
+  {
+    const char* pe = std::getenv("SPARTACUS_PIN_HOST");
+    const char* me = std::getenv("SPARTACUS_PIN_HOST_MIN_COLUMNS");
+    const bool off = pe && pe[0] == '0';
+    const int min_cols = me ? std::atoi(me) : (pe ? 4096 : 32768);
+    if (!off && c_end - c_begin >= min_cols) {
+      long call_l0 = 0, call_l1 = 0;
+      layer_range(canopy, c_begin, c_end, &call_l0, &call_l1);
+      pins_made = true;
+      pin_call_arrays(config, canopy, sw, lw, bc_out, fl, c_begin, c_end, call_l0, call_l1);
     }
-    if (pins_made) g_pins.release(/*call_owned_only=*/true);
-  };
-  auto body = [&]() -> int {
-    const int profiles = ((sw_norm_dir && sw_norm_dir->flux_dn_layer_top)
-                          || (lw_internal && lw_internal->flux_dn_layer_top)) ? 1 : 0;
-    int device = 0;
-    HIP_CHECK_THROW(hipGetDevice(&device));
-    const bool nocache = std::getenv("SPARTACUS_NO_PLAN_CACHE") != nullptr;
-    if (g_host.slot[0] && (nocache || g_host.profiles != profiles || g_host.device != device
-                           || std::memcmp(&g_host.cfg, config, sizeof(ss_config)) != 0))
-      g_host.drop();
-    g_host.cfg = *config;
-    g_host.profiles = profiles;
-    g_host.device = device;
-
-    ss_flux* fl[4] = {config->do_sw ? sw_norm_dir : nullptr, config->do_sw ? sw_norm_diff : nullptr,
-                      config->do_lw ? lw_internal : nullptr, config->do_lw ? lw_norm : nullptr};
-    const int c_begin = istartcol - 1, c_end = iendcol;
-    long call_l0 = 0, call_l1 = 0;
-    layer_range(canopy, c_begin, c_end, &call_l0, &call_l1);
-    // SPARTACUS_PIN_HOST=1: registrations owned by this call (PinRegistry); not worth their system calls
-    // for small block calls (SPARTACUS_PIN_HOST_MIN_COLUMNS, default 4096)
-    {
-      // Call-owned locks are the DEFAULT for calls of 32768 columns and more (measured on this box: locking
-      // and releasing ~1 GB per call costs ~1 ms from the second call on, the pipeline it enables takes 27 ->
-      // 17 ms off a 200 000-column call); SPARTACUS_PIN_HOST=1 lowers the threshold to
-      // SPARTACUS_PIN_HOST_MIN_COLUMNS (default 4096), SPARTACUS_PIN_HOST=0 switches locking off.
-      const char* pe = std::getenv("SPARTACUS_PIN_HOST");
-      const char* me = std::getenv("SPARTACUS_PIN_HOST_MIN_COLUMNS");
-      const bool off = pe && pe[0] == '0';
-      const int min_cols = me ? std::atoi(me) : (pe ? 4096 : 32768);
-      if (!off && c_end - c_begin >= min_cols) {
-        pins_made = true;
-        pin_call_arrays(config, canopy, sw, lw, bc_out, fl, c_begin, c_end, call_l0, call_l1);
-      }
-    }
-    // are the caller's (large) arrays page-locked - by the lines above or by ss_host_pin?
-    const bool pinned = canopy->dz && call_l1 > call_l0
-                        && g_pins.covered(canopy->dz + call_l0, sizeof(double) * (size_t)(call_l1 - call_l0));
-    const bool always_seed = std::getenv("SPARTACUS_ALWAYS_SEED") != nullptr;
-    // per-column outputs: call-level device arrays, one download per member at the end
-    const std::vector<ColumnOutput> col_out = column_outputs(config, profiles, bc_out, fl);
-    std::vector<double*> col_dev(col_out.size());
-    for (size_t i = 0; i < col_out.size(); ++i)
-      col_dev[i] = g_host.arena_get(col_out[i].name, (size_t)col_out[i].width * (size_t)(c_end - c_begin));
-    // per-layer outputs: call-level device arrays too - the sub-plans write their chunk's layer range of them,
-    // and they come home in copies that do NOT follow the chunking: one per member for every group of chunks
-    // (the download engine starts ~30 us late on every copy; 34 members x 7 chunks of such gaps were a third
-    // of a pinned 200 000-column call)
-    const std::vector<ColumnOutput> lay_out = layer_outputs(config, profiles, fl);
-    std::vector<double*> lay_dev(lay_out.size());
-    for (size_t i = 0; i < lay_out.size(); ++i)
-      lay_dev[i] = g_host.arena_get(lay_out[i].name, (size_t)lay_out[i].width * (size_t)std::max<long>(1, call_l1 - call_l0));
-    long lay_home = call_l0;       // layers [call_l0, lay_home) are on their way to the host (or there)
-    const char* de = std::getenv("SPARTACUS_HOST_DL_EVERY");
-    const int dl_every = de ? std::max(1, std::atoi(de)) : 1;
-    long col_home = c_begin;       // columns [c_begin, col_home): per-column members on their way to the host
-    int chunks_since_download = 0;
-    constexpr int NS = HostEntry::kSlots;
-    ChunkView views[NS];
-    bool inflight[NS] = {};     // kernels of the slot's chunk may still be running
-    int r = SS_OK;
-    auto fail = [&](HipPlan* p, int code) {
-      if (p) g_last_error = p->error;
-      return code;              // leave() synchronises, then drops the sub-plans
-    };
-    auto fl_of = [](ChunkView& v, int k) { return v.have_fl[k] ? &v.fl[k] : nullptr; };
-    // SPARTACUS_HOST_TIMING=1: wall-clock milliseconds of the host thread per chunk and phase (stderr)
-    const bool timing = std::getenv("SPARTACUS_HOST_TIMING") != nullptr;
-    auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t_start = now();
-    int k = 0, chunk = 0;
-    for (int c0 = c_begin; c0 < c_end; c0 += chunk, ++k) {
-      chunk = next_chunk_columns(c_end - c_begin, chunk, pinned);
-      const int c1 = std::min(c_end, c0 + chunk), s = k % NS;
-      const double ta = now();
-      HipPlan*& p = g_host.slot[s];
-      if (inflight[s]) {          // the chunk NS back used this slot: its kernels must be done before its inputs are replaced
-        p->be.sync();
-        inflight[s] = false;
-      }
-      const double tw = now();
-      ChunkView& v = views[s];
-      make_view(canopy, sw, lw, bc_out, fl, config->nsw, config->nlw, c0, c1, v);
-      const bool fresh = !p;
-      if (fresh) p = new HipPlan;
-      p->unbind_externals();      // bindings of an earlier call (other members, other sizes) end here
-      for (size_t i = 0; i < col_out.size(); ++i)
-        p->bind_external(col_out[i].name, col_dev[i] + (size_t)col_out[i].width * (size_t)(c0 - c_begin),
-                         (size_t)col_out[i].width * (size_t)(c1 - c0));
-      long chunk_l0, chunk_l1;
-      layer_range(canopy, c0, c1, &chunk_l0, &chunk_l1);
-      if (chunk_l1 <= chunk_l0) chunk_l0 = chunk_l1 = lay_home;
-      for (size_t i = 0; i < lay_out.size(); ++i)
-        p->bind_external(lay_out[i].name, lay_dev[i] + (size_t)lay_out[i].width * (size_t)(chunk_l0 - call_l0),
-                         (size_t)lay_out[i].width * (size_t)std::max<long>(1, chunk_l1 - chunk_l0));
-      if (fresh) {
-        // one stream per sub-plan: the two sub-plans then sit on two hardware queues of their own, and
-        // what this entry has to hide is PCIe time, not the (shorter) kernel time
-        p->pipes_cap = 1;
-        ++g_host.creations;
-        g_host.streams();
-        // (a second download stream taken in turn by successive chunks, to fill the start-up gaps
-        // between a chunk's ~60 copies, was measured slower: 1.04e7 -> 0.84e7 columns/s - more
-        // streams than hardware queues)
-        if (!std::getenv("SPARTACUS_HOST_ONE_STREAM")) p->be.set_transfer_streams(g_host.up, g_host.down);
-        r = p->create(config, &v.can, sw ? &v.sw : nullptr, lw ? &v.lw : nullptr, 1, c1 - c0, profiles);
-      } else {
-        // no wait: the copies of this chunk stay queued in front of its kernels (the caller's
-        // arrays are ours until this entry returns); page-locked arrays then move by DMA while
-        // the host thread goes on
-        r = p->reset(&v.can, sw ? &v.sw : nullptr, lw ? &v.lw : nullptr, 1, c1 - c0, false);
-      }
-      if (r) return fail(p, r);
-      const double tb = now();
-      p->upload_outputs(&v.bc, fl_of(v, 0), fl_of(v, 1), fl_of(v, 2), fl_of(v, 3),
-                        always_seed ? (int)HipPlan::SEED_ALL : p->seed_needed());
-      const double tc = now();
-      r = p->solve();
-      if (r) return fail(p, r);
-      const double td = now();
-      inflight[s] = true;
-      // The per-layer results of the chunks solved so far come home behind this chunk's kernels: after the
-      // first chunk (the download engine must start early), then for every second chunk and for the last.
-      ++chunks_since_download;
-      const bool last = c1 >= c_end;
-      if (k == 0 || chunks_since_download >= dl_every || last) {
-        const long upto = std::max(lay_home, chunk_l1);
-        if (upto > lay_home) {
-          hipStream_t ds = p->be.gate_downloads();      // the download stream waits for everything queued on this plan's stream
-          for (size_t i = 0; i < lay_out.size(); ++i) {
-            const size_t w = (size_t)lay_out[i].width;
-            HipBackend::copy_async(lay_out[i].host + w * (size_t)lay_home, lay_dev[i] + w * (size_t)(lay_home - call_l0),
-                                   w * (size_t)(upto - lay_home) * sizeof(double), hipMemcpyDeviceToHost, ds);
-          }
-          lay_home = upto;
+  }
+  int result = SS_OK;
+  if (devs.size() == 1) {
+    if (devs[0] != device && !hip_ok(hipSetDevice(devs[0]), "hipSetDevice")) result = SS_ERR_HIP;
+    if (result == SS_OK)
+      result = large_call_shard(host_entry(0), devs[0], config, canopy, sw, lw, bc_out, c_begin, c_end, fl, profiles);
+    if (devs[0] != device) (void)hipSetDevice(device);
+  } else {
+    // one host thread per shard: its own device, its own HostEntry (sub-plans, streams, call-level arrays), its
+    // own contiguous slices of the caller's arrays - uploads and downloads of different devices share nothing
+    // but the host's memory bandwidth, and no result ever crosses from one device to another
+    const std::vector<int> cut = shard_cuts(canopy, c_begin, c_end, (int)devs.size());
+    for (size_t k = 0; k < devs.size(); ++k) (void)host_entry(k);          // (the vector must not grow under the threads)
+    std::vector<int> rcs(devs.size(), SS_OK);
+    std::vector<std::string> errs(devs.size());
+    std::vector<std::thread> workers;
+    for (size_t k = 0; k < devs.size(); ++k) {
+      workers.emplace_back([&, k]() {
+        if (cut[k + 1] <= cut[k]) return;
+        if (hipSetDevice(devs[k]) != hipSuccess) {
+          rcs[k] = SS_ERR_HIP;
+          errs[k] = "hipSetDevice failed for a device of the host entry";
+          return;
         }
-        chunks_since_download = 0;
+        rcs[k] = large_call_shard(*g_hosts[k], devs[k], config, canopy, sw, lw, bc_out, cut[k], cut[k + 1], fl, profiles);
+        if (rcs[k] != SS_OK) errs[k] = g_last_error;      // (thread-local in the worker)
+      });
+    }
+    for (auto& w : workers) w.join();
+    for (size_t k = 0; k < devs.size(); ++k)
+      if (rcs[k] != SS_OK && result == SS_OK) {
+        result = rcs[k];
+        g_last_error = "shard " + std::to_string(k) + " (device " + std::to_string(devs[k]) + "): " + errs[k];
       }
-      if (timing)
-        std::fprintf(stderr, "host entry chunk %d (%d cols): wait for slot %.2f, view+upload %.2f, seed %.2f, solve queued %.2f, download queued %.2f ms\n",
-                     k, c1 - c0, tw - ta, tb - tw, tc - tb, td - tc, now() - td);
-    }
-    for (int s = 0; s < NS; ++s) {
-      if (!inflight[s]) continue;
-      const double te = now();
-      g_host.slot[s]->be.sync();
-      if (timing) std::fprintf(stderr, "host entry: slot %d done after %.2f ms\n", s, now() - te);
-    }
-    // every kernel of the call has completed: the per-column outputs, one copy per member.  (Measured, 200 000
-    // columns: sending them with every chunk - 27 more ~1 MB copies per download point - 17.1 -> 20.2 ms; once
-    // at two thirds of the call and once at the end 18.7 ms; all at the end 17.3 ms.  Likewise the per-layer
-    // members: with every chunk 17.3, every second 17.5, every third 18.1, all at the end 22.3 ms: the transfer
-    // is bound by the bytes, ~45 GB/s down while ~30 GB/s go up, not by the number of copies.)
-    {
-      const double te = now();
-      hipStream_t ds = g_host.down ? g_host.down : nullptr;
-      for (size_t i = 0; i < col_out.size(); ++i) {
-        const size_t w = (size_t)col_out[i].width;
-        HipBackend::copy_async(col_out[i].host + w * (size_t)col_home, col_dev[i] + w * (size_t)(col_home - c_begin),
-                               w * (size_t)(c_end - col_home) * sizeof(double), hipMemcpyDeviceToHost, ds);
-      }
-      HIP_CHECK_THROW(hipStreamSynchronize(ds));
-      if (timing) std::fprintf(stderr, "host entry: %zu per-column members home after %.2f ms\n", col_out.size(), now() - te);
-    }
-    if (timing) std::fprintf(stderr, "host entry total %.2f ms\n", now() - t_start);
-    if (nocache) g_host.drop();
-    return r;
-  };
-  return guarded([&]() -> int {
-    int r;
-    try {
-      r = body();
-    } catch (...) {
-      leave(true);
-      throw;
-    }
-    leave(r != SS_OK);
-    return r;
-  });
+  }
+  if (pins_made) g_pins.release(/*call_owned_only=*/true);
+  return result;
 }
 
 }  // extern "C"

@@ -40,7 +40,9 @@ EXPORTS = (
     "ss_plan_download", "ss_plan_last_kernel_ms", "ss_plan_eigen_failures", "ss_plan_set_pipes", "ss_plan_scale_and_sum", "ss_plan_download_sums",
     "ss_plan_device_ptr", "ss_plan_device", "ss_plan_destroy", "ss_host_entry_plan_creations",
     "ss_host_pin", "ss_host_unpin", "ss_host_unpin_all", "ss_host_pinned_bytes",
-    "ss_device_count", "ss_set_device",
+    "ss_device_count", "ss_set_device", "ss_set_devices", "ss_get_devices",
+    "ss_plan_create_multi", "ss_multi_plan_count", "ss_multi_plan_part", "ss_multi_plan_solve",
+    "ss_multi_plan_synchronize", "ss_multi_plan_download", "ss_multi_plan_destroy",
     "ss_last_error", "ss_version",
     "ss_calc_matrices_sw_eig", "ss_calc_matrices_lw_eig", "ss_eigen_decomposition_real",
     "ss_units_last_error",
@@ -89,6 +91,21 @@ def device_count():
 
 def set_device(index):
     _check(load_library().ss_set_device(C.c_int32(index)))
+
+
+def set_devices(devices):
+    """Devices of the host entry (ss_set_devices): large calls of radsurf() are cut into one contiguous column
+    shard per listed device, one host thread each.  [] = the calling thread's current device; a device may be
+    listed more than once."""
+    arr = (C.c_int32 * max(1, len(devices)))(*devices)
+    _check(load_library().ss_set_devices(arr, C.c_int32(len(devices))))
+
+
+def get_devices():
+    n = C.c_int32(0)
+    arr = (C.c_int32 * 64)()
+    _check(load_library().ss_get_devices(arr, C.c_int32(64), C.byref(n)))
+    return [arr[k] for k in range(min(64, n.value))]
 
 
 def host_pin(array):
@@ -220,6 +237,58 @@ def eigen_decomposition_real(amat, force_general_loops=False):
         C.c_int32(n), C.c_int32(nmat), _fp(a), _fp(val), _fp(vec), C.c_int32(int(force_general_loops)),
         ierr.ctypes.data_as(C.POINTER(C.c_int32))))
     return val, vec, ierr
+
+
+class MultiPlan:
+    """One column set on several devices from one process (ss_plan_create_multi): a plan per contiguous
+    column shard, each on its device; solve queues every part, download lets every part write its slices
+    of the caller's full-size objects."""
+
+    def __init__(self, config, canopy_props, sw_spectral_props, lw_spectral_props, devices,
+                 istartcol=1, iendcol=None, want_profiles=True):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        if iendcol is None:
+            iendcol = canopy_props.ncol
+        self._keep = [config.to_c(), canopy_props.to_c(), sw_spectral_props.to_c(), lw_spectral_props.to_c()]
+        arr = (C.c_int32 * len(devices))(*devices)
+        _check(self._lib.ss_plan_create_multi(C.byref(self._h), *[C.byref(k) for k in self._keep],
+                                              C.c_int32(istartcol), C.c_int32(iendcol),
+                                              C.c_int32(int(want_profiles)), arr, C.c_int32(len(devices))))
+
+    def parts(self):
+        """[(device, istartcol, iendcol)] of the shards"""
+        n = C.c_int32(0)
+        _check(self._lib.ss_multi_plan_count(self._h, C.byref(n)))
+        out = []
+        for k in range(n.value):
+            d, a, b = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+            _check(self._lib.ss_multi_plan_part(self._h, C.c_int32(k), None, C.byref(d), C.byref(a), C.byref(b)))
+            out.append((d.value, a.value, b.value))
+        return out
+
+    def solve(self):
+        _check(self._lib.ss_multi_plan_solve(self._h))
+
+    def synchronize(self):
+        _check(self._lib.ss_multi_plan_synchronize(self._h))
+
+    def download(self, bc_out, sw_norm_dir=None, sw_norm_diff=None, lw_internal=None, lw_norm=None):
+        keep = [bc_out.to_c()] + [f.to_c() if f is not None and f.nspec else None
+                                  for f in (sw_norm_dir, sw_norm_diff, lw_internal, lw_norm)]
+        _check(self._lib.ss_multi_plan_download(
+            self._h, *[C.byref(k) if k is not None else None for k in keep]))
+
+    def close(self):
+        if self._h:
+            self._lib.ss_multi_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Plan:

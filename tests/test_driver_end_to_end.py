@@ -107,12 +107,13 @@ def _unpack(packed, cp, nmaxlay):
     return out
 
 
-def _run_driver(tmp_path, nam_text, input_name):
+def _run_driver(tmp_path, nam_text, input_name, env=None):
     nam = tmp_path / "config.nam"
     nam.write_text(nam_text)
     out = tmp_path / "out.nc"
     r = subprocess.run([EXE, str(nam), os.path.join(INPUTS, input_name), str(out)],
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=600,
+                       env=None if env is None else dict(os.environ, **env))
     assert r.returncode == 0 and out.exists(), r.stdout[-2000:] + r.stderr[-2000:]
     return netcdf_file(str(out), "r", mmap=False)
 
@@ -207,4 +208,17 @@ def test_reference_driver_on_hip_single_layer(tmp_path, golden, isurfacetype, nb
     nc = _run_driver(tmp_path, NAM_SINGLE_LAYER % dict(isurfacetype=isurfacetype, nblocksize=nblocksize),
                      "test_single_layer.nc")
     n = _compare(nc, golden)
+    assert n >= 12
+
+
+def test_reference_driver_on_hip_sharded_over_devices(tmp_path):
+    """The untouched driver reaching several devices from its ONE process: SPARTACUS_DEVICES lists the devices
+    of the host entry, which cuts the call into one contiguous column shard per entry (one host thread each).
+    The test box has one GPU: two shards on device 0 (23 columns each, the chunk pipeline instead of the
+    small-call path) - same output file as the unsharded run."""
+    nam = NAM_SINGLE_LAYER % dict(isurfacetype=2, nblocksize=100)
+    nc = _run_driver(tmp_path, nam, "test_single_layer.nc",
+                     env={"SPARTACUS_DEVICES": "0,0", "SPARTACUS_SMALL_CALL_COLUMNS": "0",
+                          "SPARTACUS_SHARD_MIN_COLUMNS": "8"})
+    n = _compare(nc, "single_layer__sp")
     assert n >= 12

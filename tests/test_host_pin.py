@@ -209,3 +209,41 @@ def test_extra_members_and_pointers_toggled_between_calls():
     got3 = _solve(radsurf, case, _alloc(case))
     for k, v in base.items():
         assert np.array_equal(v, got3[k]), k
+
+
+def test_arrays_the_caller_registered_itself_keep_their_registration(monkeypatch):
+    """A caller that page-locked an array with hipHostRegister outside this library (a host model with its own
+    GPU code): the entry's call-owned locking must neither register it a second time nor take the caller's
+    registration away when the call returns (probe scenario double_register_single_unregister)."""
+    import ctypes as C
+    from spartacus_surface_amd import workloads
+    radsurf = _hip()
+    radsurf.host_unpin_all()
+    hip = C.CDLL("libamdhip64.so")
+    case = workloads.c3_vegetated_urban(ncol=NCOL, seed=9)
+    base = _solve(radsurf, case, _alloc(case))
+    dz = case["canopy"].dz
+    assert dz.flags["C_CONTIGUOUS"] and dz.nbytes > (1 << 20)
+    ptr = C.c_void_p(dz.ctypes.data)
+    assert hip.hipHostRegister(ptr, C.c_size_t(dz.nbytes), C.c_uint(0)) == 0
+    try:
+        monkeypatch.setenv("SPARTACUS_PIN_HOST", "1")
+        for _ in range(2):
+            got = _solve(radsurf, case, _alloc(case))
+            for k in base:
+                assert np.array_equal(base[k], got[k], equal_nan=True), k
+            # (measured, tools/experiments/reg_attr_probe.py: a second hipHostRegister of the range succeeds and ONE
+            # hipHostUnregister then drops the registration altogether - the device pointer is gone)
+            dev = C.c_void_p()
+            assert hip.hipHostGetDevicePointer(C.byref(dev), ptr, C.c_uint(0)) == 0, "the caller's registration is gone"
+        assert radsurf.host_pinned_bytes() == 0       # nothing of the call survives it
+    finally:
+        assert hip.hipHostUnregister(ptr) == 0        # still the caller's to release - exactly once
+    assert hip.hipHostUnregister(ptr) != 0
+
+
+def test_unpin_of_an_unknown_base_is_an_error():
+    radsurf = _hip()
+    a = np.zeros(1 << 18)
+    with pytest.raises(radsurf.SpartacusHipError):
+        radsurf.host_unpin(a)
