@@ -182,22 +182,34 @@ def parity_of_sample(case, ref_out, kind, ntruth=2048):
     return res
 
 
+def library_build_id():
+    from spartacus_surface_amd import radsurf
+    return radsurf.build_id()
+
+
 def pmc_summary(workload):
     """The committed PMC summary of the workload (profiles/traffic.json for the headline one,
     profiles/traffic_c3ns4.json for C3 with 4 streams; written by
     tools/pmc_to_profile.py from separate rocprofv3 --pmc passes; FETCH_SIZE doubled per
     MI355X_MICROARCH.md): bytes moved between L2 and the fabric and executed fp64 flops,
-    per column and kernel family."""
+    per column and kernel family.  The file is stamped with the hash of the library it was measured on:
+    counters of ANOTHER build are not used (returns (None, reason): the traffic- and flop-derived fractions
+    of the line are then null instead of silently stale)."""
     name = {"c3": "traffic.json", "c3ns4": "traffic_c3ns4.json"}.get(workload)
     if name is None:
-        return None
+        return None, "no committed PMC summary for this workload"
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
             t = json.load(f)
         t["bytes_per_column"], t["fp64_flops_per_column_executed"]     # noqa: B018
-        return t
     except (OSError, KeyError, ValueError):
-        return None
+        return None, "profiles/%s missing or unreadable" % name
+    have, want = t.get("library_build_id"), library_build_id()
+    if have != want and os.environ.get("SPARTACUS_BENCH_ANY_PMC") != "1":
+        return None, ("profiles/%s was measured on library build %s, the loaded library is %s: re-run "
+                      "tools/profile_round.sh + tools/pmc_to_profile.py (SPARTACUS_BENCH_ANY_PMC=1 overrides)"
+                      % (name, have, want))
+    return t, None
 
 
 def fp64_figure(flops_model, ncol, ms_per_step, pmc):
@@ -318,6 +330,49 @@ def other_workload(workload, ncol, steps, ncheck):
             "parity": {"columns": ncheck, "against": "oracle (C restatement, bit-identical to the reference on its test inputs)",
                        "max_rel_error": max(e_gr.values()), "where": max(e_gr, key=e_gr.get),
                        "gpu_vs_exact_max": max(e_gt.values()), "reference_vs_exact_max": max(e_rt.values())}}
+
+
+def input_refresh_figure(case, steps):
+    """The shape of the reference driver's timed loop (driver/spartacus_surface_driver.F90:195-265): every
+    repeat derives the longwave emission / Planck arrays from the temperatures (calc_simple_spectrum_lw,
+    :221-225) and calls radsurf on inputs it hands over again.  Two figures on a plan of its own, the same
+    columns with the temperatures the workload's Planck values were made from:
+      device_refresh: per step the device spectrum (ss_plan_calc_simple_spectrum_lw), the re-pack of the
+                      longwave inputs it invalidates (k_pack) and the solve - inputs stay resident;
+      host_refresh:   per step also ss_plan_upload of every input array from the host (PCIe-inclusive:
+                      never the headline value), which re-packs both spectral regions."""
+    import copy
+    import torch
+    from spartacus_surface_amd import radsurf
+    cfg, cp, sw, lw = case["config"], copy.deepcopy(case["canopy"]), case["sw"], copy.deepcopy(case["lw"])
+    t_air, t_surf = float(np.float32(278.15)), float(np.float32(283.15))
+    cp.ground_temperature = np.full(cp.ncol, t_surf)
+    for name, t in (("roof_temperature", t_surf), ("wall_temperature", t_surf), ("clear_air_temperature", t_air),
+                    ("veg_temperature", t_air), ("veg_air_temperature", t_air)):
+        setattr(cp, name, np.full(cp.ntotlay, t))
+    plan = radsurf.Plan(cfg, cp, sw, lw, want_profiles=False)
+    out = {}
+    for label, upload in (("device_refresh", False), ("host_refresh", True)):
+        def one():
+            if upload:
+                plan.upload()
+            plan.calc_simple_spectrum_lw()
+            plan.solve()
+        one()
+        plan.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        plan.synchronize()
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / steps
+        out[label] = {"value": cp.ncol / sec, "unit": "columns/s", "ms_per_step": 1e3 * sec, "steps": steps}
+    plan.close()
+    out["note"] = ("per step: calc_simple_spectrum_lw on the device + re-pack of the inputs it changes + solve "
+                   "(device_refresh); the same after re-uploading every input array from pageable host memory "
+                   "(host_refresh, PCIe-inclusive).  The headline value times the solve on unchanged resident inputs.")
+    return out
 
 
 def scale_sum_rate(plan, case, ncol):
@@ -536,7 +591,7 @@ def main():
         value = total_cols_per_step * args.steps / elapsed
         ms_per_step = 1e3 * elapsed / args.steps
         fpc = flops_per_column(case)
-        pmc = pmc_summary(args.workload)
+        pmc, pmc_stale = pmc_summary(args.workload)
         # per-GPU step time for the per-kernel figures (what one GPU's kernels see)
         if serial_ms is not None:
             roofline = roofline_block(serial_ms, serial_n, 2, my_cols, case, pmc,
@@ -564,6 +619,8 @@ def main():
             "roofline": roofline,
             "fp64": fp64_figure(fpc, my_cols, ms_per_step, pmc),
             "streams": pipes,
+            "library": {"version": radsurf.load_library().ss_version().decode(), "build_id": library_build_id(),
+                        "pmc_summary": "profiles counters of this build" if pmc else pmc_stale},
             "kernel_spans_ms_per_step": {k: v / args.steps for k, v in fam_ms.items()},
             "kernel_spans_note": "event-bracketed spans of the timed region; with streams > 1 they overlap in "
                                  "time and are NOT durations to add up or to divide bytes by",
@@ -587,10 +644,14 @@ def main():
             line["vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]
             line["pcie_inclusive"] = host_entry_rate(min(my_cols, 200_000))
         if world == 1 and not args.no_extras and args.workload == "c3":
-            # the other configurations of BASELINE.json whose kernels differ from the headline's (orders 7..16),
-            # driver-observed: n = 12 on the C3 column set, and config 5 (rami5) as a throughput workload
+            # the driver's own timed step (spectrum + re-pack + solve), then every other configuration of
+            # BASELINE.json, driver-observed: C2 (config 2), C4 (config 4, on one GPU), n = 12 on the C3 column
+            # set, and config 5 (rami5) as a throughput workload
             plan.close()
-            line["other_workloads"] = {"c3ns4": other_workload("c3ns4", 200_000, 3, 2048),
+            line["step_with_input_refresh"] = input_refresh_figure(case, 3)
+            line["other_workloads"] = {"c2": other_workload("c2", 100_000, 3, 2048),
+                                       "c3ns4": other_workload("c3ns4", 200_000, 3, 2048),
+                                       "c4": other_workload("c4", 100_000, 3, 128),
                                        "rami5": other_workload("rami5", 20_000, 3, 128)}
         print(json.dumps(line), flush=True)
     plan.close()

@@ -422,6 +422,8 @@ int ss_device_count(int32_t *count);
 int ss_set_device(int32_t device);
 const char *ss_last_error(void);
 const char *ss_version(void);
+/* hash of the sources this library was built from (csrc/Makefile): stamps the committed counter summaries */
+const char *ss_build_id(void);
 
 #ifdef __cplusplus
 }

@@ -1183,6 +1183,10 @@ int ss_set_device(int32_t device) {
 
 const char* ss_last_error(void) { return g_last_error.c_str(); }
 const char* ss_version(void) { return "spartacus_surface_hip 0.3 (gfx950)"; }
+#ifndef SS_BUILD_ID
+#define SS_BUILD_ID "unstamped"
+#endif
+const char* ss_build_id(void) { return SS_BUILD_ID; }
 
 // Devices of the host entry: large calls of spartacus_radsurf_hip cut [istartcol, iendcol] into one contiguous
 // shard per listed device (balanced by layer count), one host thread per shard.  ndevices = 0: back to the

@@ -43,7 +43,7 @@ EXPORTS = (
     "ss_device_count", "ss_set_device", "ss_set_devices", "ss_get_devices",
     "ss_plan_create_multi", "ss_multi_plan_count", "ss_multi_plan_part", "ss_multi_plan_solve",
     "ss_multi_plan_synchronize", "ss_multi_plan_download", "ss_multi_plan_destroy",
-    "ss_last_error", "ss_version",
+    "ss_last_error", "ss_version", "ss_build_id",
     "ss_calc_matrices_sw_eig", "ss_calc_matrices_lw_eig", "ss_eigen_decomposition_real",
     "ss_units_last_error",
 )
@@ -69,9 +69,10 @@ def load_library():
         _lib = C.CDLL(_LIB_PATH)
         _lib.ss_last_error.restype = C.c_char_p
         _lib.ss_version.restype = C.c_char_p
+        _lib.ss_build_id.restype = C.c_char_p
         _lib.ss_units_last_error.restype = C.c_char_p
         for name in EXPORTS:
-            if name not in ("ss_last_error", "ss_version", "ss_units_last_error"):
+            if name not in ("ss_last_error", "ss_version", "ss_build_id", "ss_units_last_error"):
                 getattr(_lib, name).restype = C.c_int
     return _lib
 
@@ -81,6 +82,11 @@ def _check(rc):
         msg = load_library().ss_last_error()
         raise SpartacusHipError("%s (%d): %s" % (STATUS.get(rc, "error"), rc,
                                                  msg.decode() if msg else ""))
+
+
+def build_id():
+    """hash of the sources the loaded library was built from (ss_build_id)"""
+    return load_library().ss_build_id().decode()
 
 
 def device_count():
