@@ -541,6 +541,9 @@ int device_ready() {
     g_last_error = "no HIP device available (this library has no CPU fallback)";
     return SS_ERR_NO_DEVICE;
   }
+  // an error the HOST left behind in this thread (a failed call of its own) is not ours: the launch checks of
+  // this library read hipGetLastError and would report it as a failed kernel launch
+  (void)hipGetLastError();
   return SS_OK;
 }
 
@@ -1243,7 +1246,8 @@ int ss_plan_create(ss_plan** plan, const ss_config* config, const ss_canopy* can
 // re-entrant: calls on ONE plan must come from one thread at a time (different
 // plans are independent - they share no stream or event).
 #define SS_PLAN_ENTRY(plan) \
-  if (!(plan)) return SS_ERR_BAD_ARGUMENT
+  if (!(plan)) return SS_ERR_BAD_ARGUMENT; \
+  (void)hipGetLastError()          /* an error the host left behind in this thread is not ours */
 
 int ss_plan_upload(ss_plan* plan, const ss_canopy* canopy, const ss_sw_spectral* sw,
                    const ss_lw_spectral* lw) {

@@ -48,7 +48,10 @@ struct SwColRec {
   static constexpr int TAIL = DBE + rec_even(N * D);
   static constexpr int EDIR = TAIL + 2 * rec_even(N * D);
 #else
-  static constexpr int EDIR = DBE + rec_even(N * D);
+  // (fused AND direct beam as a vector, ss_layer_up_sw2.hpp: DTP holds the D + 1 components just below the top
+  // interface of the layer - its regions and the exposed roofs -, E and int_dir follow)
+  static constexpr int NDTP = (FUSED && DIRVEC) ? rec_even(D + 1) : rec_even(D);
+  static constexpr int EDIR = (FUSED && DIRVEC) ? DTP + NDTP : DBE + rec_even(N * D);
 #endif
   static constexpr int IDIR = EDIR + rec_even(D * D);
   static constexpr int NELEM = FUSED ? IDIR + rec_even(D * D) : DIRVEC ? DTP + rec_even(D) : DBE + rec_even(N * D);

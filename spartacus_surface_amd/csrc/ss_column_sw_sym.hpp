@@ -544,12 +544,20 @@ SS_HD void column_up_sw(const Launch& L, int cu) {
   else column_up_sw_full<URBAN, NREG, NS>(L, cu);
 }
 
+}  // namespace ss
+#include "ss_layer_up_sw2.hpp"
+namespace ss {
+
 // Whole column on one lane (host emulation and small problems)
 // layer + upward sweep on one lane (k_layer_up): scaled coordinates where the layer record is packed
 template <bool URBAN, int NREG, int NS>
 SS_HD void layer_up_sw_any(const Launch& L, int cu) {
-  if constexpr (SwLayRec<NREG * NS, NREG>::PACKED) sym::layer_up_sw<URBAN, NREG, NS>(L, cu);
-  else layer_up_sw<URBAN, NREG, NS>(L, cu);
+  if constexpr (SwLayRec<NREG * NS, NREG>::PACKED) {
+    if constexpr (SwColRec<NREG * NS, NREG>::DIRVEC) sym::layer_up_sw2<URBAN, NREG, NS>(L, cu);
+    else sym::layer_up_sw<URBAN, NREG, NS>(L, cu);
+  } else {
+    layer_up_sw<URBAN, NREG, NS>(L, cu);
+  }
 }
 
 template <bool URBAN, int NREG, int NS>

@@ -37,6 +37,15 @@
 #ifndef SS_COOP_MIN_ORDER
 #define SS_COOP_MIN_ORDER (SS_UNROLL_MAX + 1)
 #endif
+// Shortwave, orders 3 .. SS_UNROLL_MAX: layer matrices and adding method of a column unit on ONE lane, no layer
+// record (ss_layer_up_sw2.hpp; round 4: 3.3 + 2.9 ms as two kernels -> 5.4 ms, 15 KB per column less traffic).
+// -DSS_NO_SYM_FUSE_SW2 builds the three-kernel form of round 3.
+#if !defined(SS_NO_SYM_FUSE_SW2) && !defined(SS_SYM_FUSE_SW) && !defined(SS_FUSE_SW) && !defined(SS_FUSE_LW) \
+    && !defined(SS_NO_SYM_LAYER) && !defined(SS_NO_SYM_PACK_SW) && !defined(SS_NO_SYM_PACK_COL_SW) && !defined(SS_NO_SW_DIRVEC)
+#ifndef SS_SYM_FUSE_SW2
+#define SS_SYM_FUSE_SW2 1
+#endif
+#endif
 #define SS_PRAGMA(x) _Pragma(#x)
 #define SS_UNROLL_N(N) SS_PRAGMA(unroll((N) <= SS_UNROLL_MAX ? (N) : 1))
 #define SS_UNROLL_NN(N) SS_PRAGMA(unroll((N) <= SS_UNROLL_MAX ? (N) * (N) : 1))

@@ -12,6 +12,8 @@
 #include "ss_column16.hpp"
 #include "ss_down16.hpp"
 
+#include "ss_kernel_layer_up.hpp"
+
 namespace ss {
 namespace {
 
@@ -35,9 +37,16 @@ namespace {
 
 // (first pass of the cooperative orders: scalars, element-wise Gamma stores and the small clear-sky
 // sub-problem - registers, not scratch: two waves per SIMD with 256 registers each)
+#ifndef SS_LAYER_ATTR
+#ifdef SS_LAYER_VGPR          // experiment: cap the registers of the layer kernel (VGPRs + AGPRs)
+#define SS_LAYER_ATTR __attribute__((amdgpu_num_vgpr(SS_LAYER_VGPR)))
+#else
+#define SS_LAYER_ATTR
+#endif
+#endif
 template <bool U, int R, int NS, bool LW, int STAGE = 0>
 __global__ void __launch_bounds__(kBlock, (STAGE == 1 && r16_layer(R * NS, LW)) ? 2 : SS_WAVES(R, NS, SS_MIN_WAVES_LAYER))
-    k_layer(const Launch L) {
+    SS_LAYER_ATTR k_layer(const Launch L) {
 #ifndef SS_LAYER_GRID_2D
   // Block -> (tile of 64 column units, layer).  The per-layer inputs of a column
   // sit 8 * nlay bytes apart, so one block uses 8 bytes of every 128-byte line it
@@ -74,16 +83,7 @@ __global__ void __launch_bounds__(kBlock, 1) k_eig_coop(const Launch L) {
                         L.eigen_fail ? L.eigen_fail + kSlotOneLaneUnits : nullptr, L.cfg.decline_cooperative == 2);
 }
 
-// layer matrices + upward sweep of a column unit on one lane (orders that live in registers)
-template <bool U, int R, int NS, bool LW>
-__global__ void __launch_bounds__(kBlock, 1) k_layer_up(const Launch L) {
-  const int cu = blockIdx.x * kBlock + threadIdx.x;
-  if (cu >= L.ncu) return;
-  if constexpr (fused_order(R * NS, LW)) {
-    if constexpr (LW) layer_up_lw<U, R, NS>(L, cu);
-    else layer_up_sw_any<U, R, NS>(L, cu);
-  }
-}
+// (k_layer_up: ss_kernel_layer_up.hpp)
 
 // Workgroups of the row-of-16 kernels: 128 threads = 8 units.  The records are tiled for one-lane
 // kernels ([element pair][lane][2]: the pairs of 8 neighbouring units make one 128-byte line), and
@@ -228,9 +228,14 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev, hipStream_t f
   if (ev) SS_TRY(hipEventRecord(ev[0], stream));
   if constexpr (fused_order(SS_INST_NREG * NS, SS_INST_LW != 0)) {
     // fused form: one kernel for the layer matrices and the upward sweep (the "column" span is empty)
+#if SS_INST_LW == 0 && defined(SS_INST_FUSE_NAME)
+    // (the shortwave kernel is compiled in a unit of its own, see ss_kernels.hpp)
+    { const int rc_ = SS_INST_FUSE_NAME(NS, L, stream); if (rc_ != 0) return rc_; }
+#else
     hipLaunchKernelGGL((k_layer_up<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx), dim3(kBlock), 0,
                        stream, L);
     SS_TRY(hipGetLastError());
+#endif
     if (ev) SS_TRY(hipEventRecord(ev[1], stream));
     if (ev) SS_TRY(hipEventRecord(ev[2], stream));
     SS_TRY(launch_down<NS>(L, stream));

@@ -117,6 +117,8 @@ constexpr bool fused_order(int n, bool lw);
 constexpr bool sw_dirvec(int n) {
 #if defined(SS_NO_SW_DIRVEC)
   return false && n > 0;
+#elif defined(SS_SYM_FUSE_SW2)
+  return sym_packed_col(n, false);      // the fused layer + upward kernel of round 4 carries the direct beam as a vector too
 #else
   return sym_packed_col(n, false) && !fused_order(n, false);
 #endif
@@ -328,14 +330,21 @@ constexpr bool fused_order(int n, bool lw) {
   return n <= SS_UNROLL_MAX || (false && lw);
 #elif defined(SS_FUSE_LW)
   return lw && n <= SS_UNROLL_MAX && n < SS_COOP_MIN_ORDER;
-#elif defined(SS_SYM_FUSE_LW)
-  // layer + upward sweep of the longwave on one lane, both in symmetrised coordinates (ss_column_lw_sym.hpp:
-  // sym::layer_up_lw): R^, T^ and the layer's source wait in LDS slots, no layer record exists
-  return lw && n >= 3 && n <= SS_UNROLL_MAX;
-#elif defined(SS_SYM_FUSE_SW)
-  // layer + upward sweep of the shortwave on one lane, both in symmetrised coordinates (ss_column_sw_sym.hpp:
-  // sym::layer_up_sw): R^, T^, S_up^, S_dn^ wait in the 80 LDS slots of the lane, no layer record exists
-  return !lw && n >= 3 && n <= SS_UNROLL_MAX;
+#elif defined(SS_SYM_FUSE_LW) || defined(SS_SYM_FUSE_SW) || defined(SS_SYM_FUSE_SW2)
+  // layer + upward sweep on one lane, both in symmetrised coordinates; no layer record exists.
+  //  SS_SYM_FUSE_LW  (ss_column_lw_sym.hpp: sym::layer_up_lw): R^, T^ and the layer's source wait in LDS slots;
+  //  SS_SYM_FUSE_SW  (ss_column_sw_sym.hpp: sym::layer_up_sw): R^, T^, S_up^, S_dn^ wait in the 80 LDS slots of the lane;
+  //  SS_SYM_FUSE_SW2 (ss_layer_up_sw2.hpp): the loop-carried albedo of everything below waits in LDS slots too and
+  //                  the direct beam is a vector throughout.
+  // The spectral regions are switched independently.
+  bool f = false;
+#if defined(SS_SYM_FUSE_LW)
+  if (lw && n >= 3 && n <= SS_UNROLL_MAX) f = true;
+#endif
+#if defined(SS_SYM_FUSE_SW) || defined(SS_SYM_FUSE_SW2)
+  if (!lw && n >= 3 && n <= SS_UNROLL_MAX) f = true;
+#endif
+  return f;
 #else
   return false && n > 0 && lw;
 #endif

@@ -97,6 +97,8 @@ inline int col_nelem(bool lw, const ClassKey& k) {
 #if defined(SS_FUSE_VIA_RECORD)
   return base + (lw ? ev(n * n) + ev(n) : 2 * ev(d * d) + 2 * ev(n * d));
 #else
+  // (shortwave fused with the direct beam as a vector: the direct flux below the top interface has d + 1 components)
+  if (!lw && sw_dirvec(n)) return base - ev(d) + ev(d + 1) + 2 * ev(d * d);
   return base + (lw ? ev(n * n) + ev(n) : 2 * ev(d * d));
 #endif
 }

@@ -5,9 +5,9 @@ export SPARTACUS_HIP_LIB=$PWD/spartacus_surface_amd/lib/variants/libss_$v.so
 [ "$v" = "main" ] && unset SPARTACUS_HIP_LIB
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc_$v
-timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc_$v/p1 -- python bench.py --steps 1 --warmup 0 --columns 200000 --no-cpu-baseline > gpurun_out/pmc_$v/p1.log 2>&1
-timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d gpurun_out/pmc_$v/p2 -- python bench.py --steps 1 --warmup 0 --columns 200000 --no-cpu-baseline > gpurun_out/pmc_$v/p2.log 2>&1
-timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE SQ_INSTS_SALU SQ_INSTS_FLAT SQ_INSTS_LDS --output-format csv -d gpurun_out/pmc_$v/p3 -- python bench.py --steps 1 --warmup 0 --columns 200000 --no-cpu-baseline > gpurun_out/pmc_$v/p3.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d gpurun_out/pmc_$v/p1 -- python bench.py --steps 1 --warmup 0 --columns 200000 --no-extras > gpurun_out/pmc_$v/p1.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d gpurun_out/pmc_$v/p2 -- python bench.py --steps 1 --warmup 0 --columns 200000 --no-extras > gpurun_out/pmc_$v/p2.log 2>&1
+timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE SQ_INSTS_SALU SQ_INSTS_FLAT SQ_INSTS_LDS --output-format csv -d gpurun_out/pmc_$v/p3 -- python bench.py --steps 1 --warmup 0 --columns 200000 --no-extras > gpurun_out/pmc_$v/p3.log 2>&1
 python tools/pmc_summary.py "$v"; exit 0
 import csv, glob, collections, sys
 v = sys.argv[1]
