@@ -1,0 +1,6 @@
+// Instantiation unit: the fused layer + upward kernel of the longwave, urban tiles, 1 region(s)
+#define SS_INST_URBAN true
+#define SS_INST_NREG 1
+#define SS_INST_LW 1
+#define SS_INST_FUSE_NAME launch_fuse_lw_urban_r1
+#include "ss_inst_fuse_body.hpp"

@@ -3,4 +3,5 @@
 #define SS_INST_NREG 1
 #define SS_INST_LW 1
 #define SS_INST_NAME launch_lw_urban_r1
+#define SS_INST_FUSE_NAME launch_fuse_lw_urban_r1
 #include "ss_inst_body.hpp"

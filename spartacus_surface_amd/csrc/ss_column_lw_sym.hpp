@@ -388,13 +388,99 @@ SS_HD void layer_up_lw(const Launch& L, int cu) {
   sym::lw_top<NREG, NS>(L, cidx, Aab, Sab);
 }
 
+// Second form (-DSS_SYM_FUSE_LW2, round 4): the loop-carried a_above^ / source_above^ wait in the lane's LDS slots
+// behind R^, T^ and the layer's source (50 + 22 + 6 of the 80) while the layer stage runs, instead of being
+// re-derived from the column record of the layer below (a round trip through memory and the overlap step again);
+// what the step reads of the launch descriptor it reads inside the step (SS_LAUNCH_HERE_REF: see ss_layer_up_sw2.hpp).
+template <bool URBAN, int NREG, int NS>
+SS_HD void layer_up_lw2(const Launch& L, int cu) {
+  constexpr int N = NREG * NS;
+  using LRec = LwLayRec<N>;
+  using CRec = LwColRec<N>;
+  using Lds = LaneLds<true>;
+  constexpr int kA = LRec::IFLUX + rec_even(N);                  // a_above^ (packed) behind R^, T^, source
+  constexpr int kS = kA + rec_even(kTri<N>);                     // source_above^
+  static_assert(CRec::FUSED && LRec::PACKED && CRec::PACKED && kS + N <= kLaneLdsSlots, "LDS slots of a lane");
+  constexpr long st = kRecStride;
+  const Inputs& in = L.in;
+  const int col = L.cols[cu / L.nspec];
+  const int jb = cu % L.nspec;
+  const int nlay = in.nlay[col];
+  const long cidx = (long)jb + (long)L.nspec * col;
+  const Lds lds{};
+  {
+    // ground, in the scaling of the lowest layer (or of the sky for a column without layers)
+    double Aab[kTri<N>], Sab[N], sf[NREG], rsf[NREG];
+    if (nlay > 0) {
+      lw_layer_roots<URBAN, NREG>(L, cu, 0, sf, rsf);
+    } else {
+      double frac[NREG];
+      region_fractions<URBAN, true, NREG>(0.0, 0.0, frac);
+      region_roots<NREG>(frac, sf, rsf);
+    }
+    sym::lw_ground<NREG, NS>(L.lg, in.ground_emissivity[cidx], in.ground_emission[cidx], sf, Aab, Sab);
+    if (nlay == 0) {
+      sym::lw_top<NREG, NS>(L, cidx, Aab, Sab);
+      return;
+    }
+    SS_UNROLL_FULL
+    for (int k = 0; k < kTri<N>; ++k) lds.put(kA + k, Aab[k]);
+    SS_UNROLL_FULL
+    for (int i = 0; i < N; ++i) lds.put(kS + i, Sab[i]);
+  }
+  for (int jlay = 0; jlay < nlay; ++jlay) {
+    SS_LAUNCH_HERE_REF(L, Lq);
+    double* crec = Lq.col + rec_base(jlay, Lq.maxlay, CRec::NELEM, cu);
+    {
+      const LwSymFusedWriter<N, Lds> w{&lds, crec, st, (unsigned long long*)Lq.eigen_fail};
+      layer_unit_lw<URBAN, NREG, NS>(Lq, cu, jlay, w);
+    }
+    double sf[NREG], rsf[NREG];
+    lw_layer_roots<URBAN, NREG>(Lq, cu, jlay, sf, rsf);
+    double dsc[N], rd[N];
+    SS_UNROLL_FULL
+    for (int r = 0; r < NREG; ++r) {
+      SS_UNROLL_FULL
+      for (int s = 0; s < NS; ++s) {
+        dsc[s + r * NS] = sf[r] * Lq.lg.sqrt_wmu[s];
+        rd[s + r * NS] = rsf[r] * Lq.lg.rsqrt_wmu[s];
+      }
+    }
+    double Aab[kTri<N>], Sab[N];
+    SS_UNROLL_FULL
+    for (int k = 0; k < kTri<N>; ++k) Aab[k] = lds.get(kA + k);
+    SS_UNROLL_FULL
+    for (int i = 0; i < N; ++i) Sab[i] = lds.get(kS + i);
+    const LwSymFusedSource<N, Lds> src{&lds};
+    double Abe[kTri<N>], Sbe[N];
+    sym::lw_up_step<N>(src, Aab, Sab, crec, dsc, rd, Abe, Sbe);
+    double sfu[NREG], rsfu[NREG];
+    sym::lw_overlap_above<URBAN, NREG, NS>(Lq, cu, jlay, nlay, Abe, Sbe, sf, rsf, sfu, rsfu, Aab, Sab);
+    if (jlay + 1 < nlay) {
+      SS_UNROLL_FULL
+      for (int k = 0; k < kTri<N>; ++k) lds.put(kA + k, Aab[k]);
+      SS_UNROLL_FULL
+      for (int i = 0; i < N; ++i) lds.put(kS + i, Sab[i]);
+    } else {
+      sym::lw_top<NREG, NS>(Lq, cidx, Aab, Sab);
+    }
+  }
+}
+
 }  // namespace sym
 
 // layer + upward sweep on one lane (k_layer_up)
 template <bool URBAN, int NREG, int NS>
 SS_HD void layer_up_lw(const Launch& L, int cu) {
-  if constexpr (LwLayRec<NREG * NS>::PACKED && LwColRec<NREG * NS>::PACKED) sym::layer_up_lw<URBAN, NREG, NS>(L, cu);
-  else layer_up_lw_full<URBAN, NREG, NS>(L, cu);
+  if constexpr (LwLayRec<NREG * NS>::PACKED && LwColRec<NREG * NS>::PACKED) {
+#if defined(SS_SYM_FUSE_LW2)
+    sym::layer_up_lw2<URBAN, NREG, NS>(L, cu);
+#else
+    sym::layer_up_lw<URBAN, NREG, NS>(L, cu);
+#endif
+  } else {
+    layer_up_lw_full<URBAN, NREG, NS>(L, cu);
+  }
 }
 
 // The upward sweep of one column unit (k_column): in symmetrised coordinates where the records are packed

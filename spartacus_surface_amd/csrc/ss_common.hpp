@@ -45,6 +45,11 @@
 #ifndef SS_SYM_FUSE_SW2
 #define SS_SYM_FUSE_SW2 1
 #endif
+// ... and the longwave likewise (sym::layer_up_lw2, ss_column_lw_sym.hpp: 3.05 + 2.0 ms -> 4.96 ms, 14 KB per
+// column less traffic); -DSS_NO_SYM_FUSE_LW2: the three-kernel form
+#if !defined(SS_NO_SYM_FUSE_LW2) && !defined(SS_SYM_FUSE_LW) && !defined(SS_SYM_FUSE_LW2)
+#define SS_SYM_FUSE_LW2 1
+#endif
 #endif
 #define SS_PRAGMA(x) _Pragma(#x)
 #define SS_UNROLL_N(N) SS_PRAGMA(unroll((N) <= SS_UNROLL_MAX ? (N) : 1))

@@ -228,8 +228,8 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev, hipStream_t f
   if (ev) SS_TRY(hipEventRecord(ev[0], stream));
   if constexpr (fused_order(SS_INST_NREG * NS, SS_INST_LW != 0)) {
     // fused form: one kernel for the layer matrices and the upward sweep (the "column" span is empty)
-#if SS_INST_LW == 0 && defined(SS_INST_FUSE_NAME)
-    // (the shortwave kernel is compiled in a unit of its own, see ss_kernels.hpp)
+#if defined(SS_INST_FUSE_NAME)
+    // (the fused kernel is compiled in a unit of its own, see ss_kernels.hpp)
     { const int rc_ = SS_INST_FUSE_NAME(NS, L, stream); if (rc_ != 0) return rc_; }
 #else
     hipLaunchKernelGGL((k_layer_up<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx), dim3(kBlock), 0,

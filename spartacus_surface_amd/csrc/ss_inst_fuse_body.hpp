@@ -1,6 +1,6 @@
-// ss_inst_fuse_body.hpp - body of the inst_fuse_sw_*.hip units: the fused layer + upward kernel of the shortwave
-// for one (tile kind, regions) class, every stream count whose order is a fused one.  The including file defines
-// SS_INST_URBAN, SS_INST_NREG and SS_INST_FUSE_NAME.
+// ss_inst_fuse_body.hpp - body of the inst_fuse_{sw,lw}_*.hip units: the fused layer + upward kernel of one
+// (tile kind, regions, spectral region) class, every stream count whose order is a fused one.  The including file
+// defines SS_INST_URBAN, SS_INST_NREG, SS_INST_LW and SS_INST_FUSE_NAME.
 #include "ss_kernel_layer_up.hpp"
 
 namespace ss {
@@ -8,10 +8,10 @@ namespace {
 
 template <int NS>
 int launch_fused_ns(const Launch& L, hipStream_t stream) {
-  if constexpr (fused_order(SS_INST_NREG * NS, false)) {
+  if constexpr (fused_order(SS_INST_NREG * NS, SS_INST_LW != 0)) {
     if (L.ncu <= 0 || L.maxlay <= 0) return 0;
     const unsigned gx = (unsigned)((L.ncu + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL((k_layer_up<SS_INST_URBAN, SS_INST_NREG, NS, false>), dim3(gx), dim3(kBlock), 0, stream, L);
+    hipLaunchKernelGGL((k_layer_up<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx), dim3(kBlock), 0, stream, L);
     return (int)hipGetLastError();
   } else {
     return (int)hipErrorInvalidValue;

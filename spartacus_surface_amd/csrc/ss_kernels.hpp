@@ -38,9 +38,9 @@ SS_DECL_LAUNCHER(launch_lw_urban_r1);
 SS_DECL_LAUNCHER(launch_lw_urban_r2);
 SS_DECL_LAUNCHER(launch_lw_urban_r3);
 
-// The fused layer + upward kernel of the shortwave (k_layer_up, ss_layer_up_sw2.hpp) lives in units of its own
-// (inst_fuse_sw_*.hip): it is compiled WITHOUT machine LICM (csrc/Makefile), which the other kernels of the class
-// are better off with.  Launches the kernel for stream count ns over the units of L; hipErrorInvalidValue when the
+// The fused layer + upward kernels (k_layer_up: ss_layer_up_sw2.hpp, sym::layer_up_lw2) live in units of their own
+// (inst_fuse_{sw,lw}_*.hip): they are compiled WITHOUT machine LICM (csrc/Makefile), which the other kernels of a
+// class are better off with.  Launches the kernel for stream count ns over the units of L; hipErrorInvalidValue when the
 // order is not a fused one.
 #define SS_DECL_FUSED(name) int name(int ns, const Launch& L, hipStream_t stream)
 SS_DECL_FUSED(launch_fuse_sw_forest_r2);
@@ -48,5 +48,10 @@ SS_DECL_FUSED(launch_fuse_sw_forest_r3);
 SS_DECL_FUSED(launch_fuse_sw_urban_r1);
 SS_DECL_FUSED(launch_fuse_sw_urban_r2);
 SS_DECL_FUSED(launch_fuse_sw_urban_r3);
+SS_DECL_FUSED(launch_fuse_lw_forest_r2);
+SS_DECL_FUSED(launch_fuse_lw_forest_r3);
+SS_DECL_FUSED(launch_fuse_lw_urban_r1);
+SS_DECL_FUSED(launch_fuse_lw_urban_r2);
+SS_DECL_FUSED(launch_fuse_lw_urban_r3);
 
 }  // namespace ss

@@ -330,7 +330,7 @@ constexpr bool fused_order(int n, bool lw) {
   return n <= SS_UNROLL_MAX || (false && lw);
 #elif defined(SS_FUSE_LW)
   return lw && n <= SS_UNROLL_MAX && n < SS_COOP_MIN_ORDER;
-#elif defined(SS_SYM_FUSE_LW) || defined(SS_SYM_FUSE_SW) || defined(SS_SYM_FUSE_SW2)
+#elif defined(SS_SYM_FUSE_LW) || defined(SS_SYM_FUSE_LW2) || defined(SS_SYM_FUSE_SW) || defined(SS_SYM_FUSE_SW2)
   // layer + upward sweep on one lane, both in symmetrised coordinates; no layer record exists.
   //  SS_SYM_FUSE_LW  (ss_column_lw_sym.hpp: sym::layer_up_lw): R^, T^ and the layer's source wait in LDS slots;
   //  SS_SYM_FUSE_SW  (ss_column_sw_sym.hpp: sym::layer_up_sw): R^, T^, S_up^, S_dn^ wait in the 80 LDS slots of the lane;
@@ -338,7 +338,7 @@ constexpr bool fused_order(int n, bool lw) {
   //                  the direct beam is a vector throughout.
   // The spectral regions are switched independently.
   bool f = false;
-#if defined(SS_SYM_FUSE_LW)
+#if defined(SS_SYM_FUSE_LW) || defined(SS_SYM_FUSE_LW2)
   if (lw && n >= 3 && n <= SS_UNROLL_MAX) f = true;
 #endif
 #if defined(SS_SYM_FUSE_SW) || defined(SS_SYM_FUSE_SW2)
