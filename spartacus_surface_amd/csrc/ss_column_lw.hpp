@@ -615,6 +615,30 @@ SS_HD void column_down_lw(const Launch& L, int cu, int pass, double* slot) {
       }
     }
   }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SS_NO_TRANSPOSED_OUT)
+  // a wave that owns one contiguous block of the caller's arrays writes it with transposed stores (see column_down_sw)
+  if constexpr (N <= SS_UNROLL_MAX) {
+    int first_l0 = 0;
+    if (wave_owns_contiguous_block(col, nlay, l0, nspec, L.maxlay, &first_l0)) {
+      const int lane = (int)(threadIdx.x & 63), nelem = 32 * nlay;
+      SS_UNROLL_FULL
+      for (int pz = 0; pz < 2; ++pz) {
+        SS_UNROLL_FULL
+        for (int s_ = 0; s_ < 7; ++s_) {
+          double* p_ = (pz == 0 ? L.flux_a : L.flux_b).f[kLwDownSlotField[s_]];
+          if (s_ < nbuf && p_) {
+            p_ += first_l0;
+            for (int e = lane; e < nelem; e += 64) {
+              const int cr = e / nlay, jl = e - cr * nlay;
+              p_[e] = obuf.get_at(s_ * L.maxlay + jl, 2 * cr + pz);
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
+#endif
   // the staged per-layer fields, all layers of a field back to back
   SS_UNROLL_FULL
   for (int s_ = 0; s_ < 7; ++s_) {

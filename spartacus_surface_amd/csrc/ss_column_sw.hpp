@@ -821,6 +821,37 @@ SS_HD void column_down_sw(const Launch& L, int cu, int pass) {
     if (jb == itransp && FSEL(F_GROUND_SUNLIT_FRAC))
       FSEL(F_GROUND_SUNLIT_FRAC)[col] = dirpass ? gdd / (cos_sza * flux_dn_dir_clear) : 0.0;
   }
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SS_NO_TRANSPOSED_OUT)
+  // The staged per-layer fields of a wave that owns one contiguous block of the caller's arrays: transposed
+  // (wave_owns_contiguous_block, ss_common.hpp) - element e of the block is layer e % nlay of column unit e / nlay
+  // of the wave, i.e. of lane 2 (e / nlay) + pass.
+  if constexpr (N <= SS_UNROLL_MAX) {
+    int first_l0 = 0;
+    if (wave_owns_contiguous_block(col, nlay, l0, nspec, L.maxlay, &first_l0)) {
+      const int lane = (int)(threadIdx.x & 63), nelem = 32 * nlay;
+      SS_UNROLL_FULL
+      for (int pz = 0; pz < 2; ++pz) {
+        SS_UNROLL_FULL
+        for (int s_ = 0; s_ < kSwDownFields; ++s_) {
+          double* p_ = (pz == 0 ? L.flux_a : L.flux_b).f[kSwDownSlotField[s_]];
+          const bool zero_ = s_ >= kSwDownDiffuseFields && pz == 1;
+          if (p_ && (zero_ || staged(s_))) {
+            p_ += first_l0;
+            for (int e = lane; e < nelem; e += 64) {
+              const int cr = e / nlay, jl = e - cr * nlay;
+              double v_ = 0.0;
+              if (!zero_)
+                v_ = s_ < kSwDownOwnFields ? obuf.get_at(s_ * L.maxlay + jl, 2 * cr + pz)
+                                           : obuf.get_at(kSwDownDiffuseFields * L.maxlay + jl, 2 * cr + 1);
+              p_[e] = v_;
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
+#endif
   // the staged per-layer fields, all layers of a field back to back
   SS_UNROLL_FULL
   for (int s_ = 0; s_ < kSwDownFields; ++s_) {

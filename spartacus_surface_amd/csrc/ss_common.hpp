@@ -118,6 +118,8 @@ struct LaneLds {
   // the same slot of the NEXT lane (an even lane borrowing what its odd neighbour leaves unused)
   SS_HD void put_next(int slot, double v) const { p[slot * 64 + 1] = v; }
   SS_HD double get_next(int slot) const { return p[slot * 64 + 1]; }
+  // a slot of ANY lane of the wave (the transposed write-out of the downward kernels)
+  SS_HD double get_at(int slot, int lane) const { return (p - threadIdx.x)[slot * 64 + lane]; }
 #else
   mutable double a[kLaneLdsSlots] = {};
   mutable double b[kLaneLdsSlots] = {};
@@ -147,6 +149,23 @@ struct LaneLdsN {
   SS_HD double get(int slot) const { return a[slot]; }
 #endif
 };
+// Do the (column, pass) lanes of this wave - a full wave of 32 column units x 2 passes, one band - own one
+// CONTIGUOUS block of the caller's per-layer arrays: consecutive columns, equal layer counts, layers packed in
+// column order?  Then the staged per-layer outputs of the downward kernels leave through transposed stores -
+// every store instruction writes 512 consecutive bytes, four complete lines - instead of 8 bytes per lane at a
+// stride of nlay x 8 bytes, which L2 has to merge and, under the pressure of the record traffic, evicts half
+// merged.  first_l0: the block's first packed layer.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ bool wave_owns_contiguous_block(int col, int nlay, int l0, int nspec, int maxlay, int* first_l0) {
+  const int lane = (int)(threadIdx.x & 63);
+  const bool full = __popcll(__ballot(1)) == 64;
+  const int col0 = __builtin_amdgcn_readfirstlane(col), l00 = __builtin_amdgcn_readfirstlane(l0);
+  const bool mine = nspec == 1 && nlay == maxlay && col == col0 + (lane >> 1) && l0 == l00 + (lane >> 1) * nlay;
+  *first_l0 = l00;
+  return full && __all(mine ? 1 : 0);
+}
+#endif
+
 // Orders above SS_UNROLL_MAX run four waves per SIMD: no LDS to spare, nothing staged
 template <>
 struct LaneLds<false> {
