@@ -100,3 +100,48 @@ def test_emulated_deep_columns_vs_oracle(emul):
     bad = fixture_io.parity_violations(fixture_io.flatten_outputs(out), ref, noise, truth=truth,
                                        noise_arr=noise_arr, slack=2.0)
     assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("flag,what", [
+    # the shortwave downward sweep with both passes on one lane (csrc/ss_down_sw_both.hpp): off by default on the
+    # device (slower, measured), kept correct: same bits as the paired-lane form under gcc
+    ("-DSS_DOWN_BOTH", "bits"),
+    # the three-kernel form of round 3 (layer records, upward sweep as a kernel of its own) against the fused
+    # kernels of round 4 (ss_layer_up_sw2.hpp, sym::layer_up_lw2): the same algebra in another order
+    ("-DSS_NO_SYM_FUSE_SW2", 1.0e-8)])
+@pytest.mark.skipif(os.environ.get("SPARTACUS_SLOW_TESTS") != "1",
+                    reason="two more builds of the emulator (3 minutes each): SPARTACUS_SLOW_TESTS=1")
+def test_alternative_kernel_forms_agree(flag, what, tmp_path):
+    """Build the emulator a second time with the flag and run three goldens through both (both pass: round 4)."""
+    import ctypes as C
+    import subprocess
+    import numpy as np
+    from tests import emul as e
+    e.build()
+    alt = str(tmp_path / "libss_emul_alt.so")
+    subprocess.run(["g++"] + e.CXXFLAGS + [flag, "-o", alt, os.path.join(os.path.dirname(e.__file__), "ss_emul.cpp")],
+                   check=True)
+    have = {os.path.basename(p)[:-4]: p for p in golden_files()}
+    names = [n for n in ("urban__2stream", "extra__ragged-tiles", "simple__test_surfaces") if n in have]
+    res = {}
+    keep = e._lib
+    try:
+        for tag, lib in (("a", e.LIB), ("b", alt)):
+            e._lib = C.CDLL(lib)
+            for n in names:
+                case, _ = fixture_io.load_case(have[n])
+                out, nfail = e.run_emul(case["config"], case["canopy"], case["sw"], case["lw"],
+                                        want_profiles=case["want_profiles"],
+                                        do_simple_spectrum=case["do_simple_spectrum"])
+                assert nfail == 0
+                res[(tag, n)] = {k: np.array(v, copy=True) for k, v in fixture_io.flatten_outputs(out).items()}
+    finally:
+        e._lib = keep
+    for n in names:
+        a, b = res[("a", n)], res[("b", n)]
+        for k in a:
+            if what == "bits":
+                assert np.array_equal(a[k], b[k], equal_nan=True), (n, k)
+            else:
+                den = np.maximum(np.abs(a[k]), 1.0e-3 * max(1.0e-300, float(np.max(np.abs(a[k])))) if a[k].size else 1.0)
+                assert np.all(np.abs(a[k] - b[k]) <= what * den), (n, k)
