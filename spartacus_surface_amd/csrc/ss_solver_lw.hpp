@@ -261,10 +261,7 @@ SS_HD_NOINLINE void layer_unit_lw_cold(const Launch* Lp, int cu, int jlay, doubl
 // W: RecWriter (HBM layer record) or the FusedWriter of k_layer_up (ss_layer_matrices.hpp)
 // (STAGE: see layer_unit_sw)
 template <bool URBAN, int NREG, int NS, class W, int STAGE = 0, bool GENERAL = false>
-SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w, const LwLayerIn<URBAN, NREG>* raw_pre = nullptr,
-                         double wall_emis1_pre = 0.0) {
-  // (raw_pre / wall_emis1_pre: the unit's inputs if the caller has loaded them already - the fused kernel
-  // requests them a layer ahead)
+SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w) {
   SS_STAMP_DECL((unsigned long long*)L.eigen_fail);
   constexpr int N = NREG * NS;
   const Inputs& in = L.in;
@@ -277,14 +274,9 @@ SS_HD void layer_unit_lw(const Launch& L, int cu, int jlay, const W& w, const Lw
   double wall_emis1 = 0.0;
   constexpr bool kEarlyPack = (STAGE == 0) || !r16_layer(NREG * NS, true);
   if constexpr (kEarlyPack) {
-    if (raw_pre) {
-      raw = *raw_pre;
-      wall_emis1 = wall_emis1_pre;
-    } else {
-      raw.load_pack(pack_rec(L, jlay, cu, kPackLw));
-      if (URBAN) wall_emis1 = rec_pair_load(pack_rec(L, jlay, cu - jb, kPackLw) + 16 * kRecStride).x;
-      SS_LOAD_FENCE();
-    }
+    raw.load_pack(pack_rec(L, jlay, cu, kPackLw));
+    if (URBAN) wall_emis1 = rec_pair_load(pack_rec(L, jlay, cu - jb, kPackLw) + 16 * kRecStride).x;
+    SS_LOAD_FENCE();
     if (raw.g.dz == kPackNoLayer) return;      // (the pack record says whether the column has this layer: ss_pack.hpp)
   } else {
     if (jlay >= in.nlay[col]) return;

@@ -281,9 +281,8 @@ SS_HD void layer_first_sw(const Launch& L, int cu, int jlay, const W& w) {
 // STAGE (orders of the cooperative eigen-solver, ss_eigen_coop.hpp): 0 = everything here;
 // 1 = first pass: only the factor W of the full problem goes to the eigen record;
 // 2 = second pass: everything, with the eigen-decomposition taken from the record.
-// pk_pre: the unit's pack record if the caller has loaded it already (the fused kernel requests it a layer ahead)
 template <bool URBAN, int NREG, int NS, class W, int STAGE = 0, bool GENERAL = false>
-SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w, const double* pk_pre = nullptr) {
+SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
   SS_STAMP_DECL((unsigned long long*)L.eigen_fail);
   constexpr int N = NREG * NS, D = NREG;
   const Inputs& in = L.in;
@@ -296,13 +295,8 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w, const do
   double pk[kPackSw];
   constexpr bool kEarlyPack = (STAGE == 0) || !r16_layer(NREG * NS, false);
   if constexpr (kEarlyPack) {
-    if (pk_pre) {
-      SS_UNROLL_FULL
-      for (int k = 0; k < kPackSw; ++k) pk[k] = pk_pre[k];
-    } else {
-      rec_load<kPackSw>(pack_rec(L, jlay, cu, kPackSw), kRecStride, 0, pk);
-      SS_LOAD_FENCE();
-    }
+    rec_load<kPackSw>(pack_rec(L, jlay, cu, kPackSw), kRecStride, 0, pk);
+    SS_LOAD_FENCE();
   }
   double cos_in;
   if constexpr (kEarlyPack) {
