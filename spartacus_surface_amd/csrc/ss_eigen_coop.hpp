@@ -277,20 +277,49 @@ __device__ __forceinline__ double group_sum(double x) {
 // the layer kernel like a declined unit: status 0 and one more in the counter "one_lane_units" that wakes that
 // pass.  force_redo (diagnostic, SPARTACUS_DECLINE_COOP=2) does that to every problem AFTER the iteration, so
 // that the hand-over itself is covered by the goldens.
+#if defined(__HIP_DEVICE_COMPILE__)
+// the partner lane's value in a group of 2 (quad_perm [1, 0, 3, 2]): two DPP moves instead of two ds_bpermute
+// round trips through the LDS pipe
+__device__ __forceinline__ double pair_swap(double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), 0xB1, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), 0xB1, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <>
+__device__ __forceinline__ double group_sum<2>(double x) { return x + pair_swap(x); }
+#endif
+
+// One-sided Jacobi WITHOUT an accumulated rotation matrix (round 4, second session).  K = W^T W = Y S^2 Y^T is what
+// the layer matrices need.  Rotating the columns of W needs Y accumulated beside it (Y = the product of the
+// rotations); rotating the columns of G = W^T = L^T F does not: G V = Q S with orthonormal Q gives K = G G^T =
+// Q S^2 Q^T, i.e. Y = Q = the rotated columns themselves, normalised.  Half the multiply-adds per rotation, and
+// the state of a lane drops from 156 to 84 doubles (order 12, 2 lanes): the kernel fits two waves per SIMD, where
+// the scalar instructions of one wave issue beside the vector instructions of the other
+// (tools/experiments/issue_probe.hip: one wave alone issues ANY instruction every ~4.8 cycles).
+#ifndef SS_JACOBI_ACCUMULATE
+#define SS_JACOBI_ACCUMULATE 0      // 1: the form of rounds 2-3 (columns of W, Y accumulated)
+#endif
+constexpr bool kJacobiAccumulate = SS_JACOBI_ACCUMULATE != 0;
+
 template <int N, int G>
 SS_HD void coop_eig_unit(double* rec, long stride, int q, unsigned long long* one_lane_units = nullptr,
                          bool force_redo = false) {
   constexpr int NR = (N + G - 1) / G;
+  constexpr int NY = kJacobiAccumulate ? NR : 1;
   using Rec = EigRec<N>;
   if (!(rec_elem_load(rec, stride, Rec::STATUS) > 0.5)) return;   // same for the whole group
-  double w[NR][N], y[NR][N], nrm[N];
+  double w[NR][N], y[NY][N], nrm[N];
   SS_UNROLL_FULL
   for (int r = 0; r < NR; ++r) {
     const int i = q + r * G;
     SS_UNROLL_FULL
     for (int j = 0; j < N; ++j) {
-      w[r][j] = (i < N) ? rec_elem_load(rec, stride, Rec::W + i * N + j) : 0.0;
-      y[r][j] = (i == j) ? 1.0 : 0.0;
+      if constexpr (kJacobiAccumulate) {
+        w[r][j] = (i < N) ? rec_elem_load(rec, stride, Rec::W + i * N + j) : 0.0;
+        y[r][j] = (i == j) ? 1.0 : 0.0;
+      } else {
+        w[r][j] = (i < N) ? rec_elem_load(rec, stride, Rec::W + j * N + i) : 0.0;      // G = W^T
+      }
     }
   }
   auto gsum = [](double v) {
@@ -340,11 +369,14 @@ SS_HD void coop_eig_unit(double* rec, long stride, int q, unsigned long long* on
           nrm[c] = acc + t * apc;
           SS_UNROLL_FULL
           for (int r = 0; r < NR; ++r) {
-            const double wp = w[r][p], wc = w[r][c], yp = y[r][p], yc = y[r][c];
+            const double wp = w[r][p], wc = w[r][c];
             w[r][p] = cs * wp - sn * wc;
             w[r][c] = sn * wp + cs * wc;
-            y[r][p] = cs * yp - sn * yc;
-            y[r][c] = sn * yp + cs * yc;
+            if constexpr (kJacobiAccumulate) {
+              const double yp = y[r][p], yc = y[r][c];
+              y[r][p] = cs * yp - sn * yc;
+              y[r][c] = sn * yp + cs * yc;
+            }
           }
         }
       }
@@ -361,6 +393,7 @@ SS_HD void coop_eig_unit(double* rec, long stride, int q, unsigned long long* on
     s = gsum(s);
     if (!(s > 0.0 && s < 1.0e300)) bad = true;      // (the same on every lane of the group)
     if (q == (j % G)) rec_elem_store(rec, stride, Rec::EV + j, s);
+    nrm[j] = s;
   }
   if (bad) {
     if (q == 0) {
@@ -375,12 +408,20 @@ SS_HD void coop_eig_unit(double* rec, long stride, int q, unsigned long long* on
     }
     return;
   }
+  if constexpr (!kJacobiAccumulate) {
+    // Y = the rotated columns, normalised (IEEE square root and division: once per column)
+    SS_UNROLL_FULL
+    for (int j = 0; j < N; ++j) nrm[j] = 1.0 / sqrt(nrm[j]);
+  }
   SS_UNROLL_FULL
   for (int r = 0; r < NR; ++r) {
     const int i = q + r * G;
     if (i < N) {
       SS_UNROLL_FULL
-      for (int j = 0; j < N; ++j) rec_elem_store(rec, stride, Rec::W + i * N + j, y[r][j]);
+      for (int j = 0; j < N; ++j) {
+        if constexpr (kJacobiAccumulate) rec_elem_store(rec, stride, Rec::W + i * N + j, y[r][j]);
+        else rec_elem_store(rec, stride, Rec::W + i * N + j, w[r][j] * nrm[j]);
+      }
     }
   }
 }

@@ -70,8 +70,12 @@ __global__ void __launch_bounds__(kBlock, (STAGE == 1 && r16_layer(R * NS, LW)) 
 
 // cooperative eigen-solver between the two passes of the layer kernel (ss_eigen_coop.hpp):
 // block -> (tile of 64 units, layer, quarter of the tile); 4 lanes per unit, 16 units per wave
+// (two waves per SIMD since the rotations are no longer accumulated: 84 doubles of state per lane at order 12)
+#ifndef SS_EIG_COOP_WAVES
+#define SS_EIG_COOP_WAVES (kJacobiAccumulate ? 1 : 2)
+#endif
 template <int N>
-__global__ void __launch_bounds__(kBlock, 1) k_eig_coop(const Launch L) {
+__global__ void __launch_bounds__(kBlock, SS_EIG_COOP_WAVES) k_eig_coop(const Launch L) {
   constexpr int G = coop_lanes(N);
   const int part = blockIdx.x % G, tl = blockIdx.x / G;
   const int tile = tl / L.maxlay, jlay = tl % L.maxlay;
