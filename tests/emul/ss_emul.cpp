@@ -1,3 +1,5 @@
+#include <cstdio>
+#include <cstdlib>
 // ss_emul.cpp - TEST-ONLY host build of the kernel bodies.
 //
 // The per-unit functions of spartacus_surface_amd/csrc (layer_unit_*,
@@ -79,6 +81,18 @@ struct EmulBackend {
               if (ss::r16_layer(NN, lw) && ss::rec_elem_load(erec, ss::kRecStride, ss::EigRec<NN>::STATUS) > 0.5)
                 lw ? ss::r16::eig_pre_scalars<U, R, NS, true>(L.lg, erec, ss::kRecStride, L.eigen_fail ? L.eigen_fail + ss::kSlotOneLaneUnits : nullptr)
                    : ss::r16::eig_pre_scalars<U, R, NS, false>(L.lg, erec, ss::kRecStride, L.eigen_fail ? L.eigen_fail + ss::kSlotOneLaneUnits : nullptr);
+              if (const char* dump = getenv("SS_EMUL_DUMP_W")) {   // prototyping aid: the Jacobi kernel's input matrices
+                if (ss::rec_elem_load(erec, ss::kRecStride, ss::EigRec<NN>::STATUS) > 0.5) {
+                  FILE* f = fopen(dump, "ab");
+                  double hdr = NN;
+                  fwrite(&hdr, 8, 1, f);
+                  for (int e = 0; e < NN * NN; ++e) {
+                    const double v = ss::rec_elem_load(erec, ss::kRecStride, ss::EigRec<NN>::W + e);
+                    fwrite(&v, 8, 1, f);
+                  }
+                  fclose(f);
+                }
+              }
               ss::coop_eig_unit<NN, 1>(erec, ss::kRecStride, 0, L.eigen_fail ? L.eigen_fail + ss::kSlotOneLaneUnits : nullptr,
                                        L.cfg.decline_cooperative == 2);
               if (ss::r16_layer(NN, lw) && ss::rec_elem_load(erec, ss::kRecStride, ss::EigRec<NN>::STATUS) > 0.5) {
