@@ -103,7 +103,10 @@ SS_HD void static_loop(F&& f) {
 // 512-byte row).  Their blocks are one wave (kBlock = 64) and they run one wave
 // per SIMD, so four blocks share the 160 KB of a CU: 40 KB = 80 doubles per lane.
 // Host builds (the emulator of tests/emul) use a plain array.
-constexpr int kLaneLdsSlots = 80;
+#ifndef SS_LANE_LDS_SLOTS
+#define SS_LANE_LDS_SLOTS 80      // (experiment builds: 40 = two waves per SIMD in the kernels that stage in LDS)
+#endif
+constexpr int kLaneLdsSlots = SS_LANE_LDS_SLOTS;
 template <bool ON>
 struct LaneLds {
   static constexpr int kSlots = kLaneLdsSlots;

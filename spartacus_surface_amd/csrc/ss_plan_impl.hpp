@@ -367,6 +367,7 @@ class Plan {
     want_profiles = profiles != 0;
     const char* mb = std::getenv("SPARTACUS_SCRATCH_MB");
     scratch_budget_bytes = (mb ? (size_t)std::atol(mb) : (size_t)4096) << 20;
+    if (const char* mcu = std::getenv("SPARTACUS_MIN_CHUNK_UNITS")) min_chunk_units = (size_t)std::max(64L, std::atol(mcu));
     const char* cpp = std::getenv("SPARTACUS_CHUNKS_PER_PIPE");
     chunks_per_pipe = cpp ? std::max(0, std::atoi(cpp)) : 4;
     const char* np = std::getenv("SPARTACUS_PIPES");
@@ -629,8 +630,12 @@ class Plan {
   // kernels bandwidth-bound, and the pipes only overlap the two kinds when they are in different phases -
   // with one chunk per pipe all of them run their layer kernel together and then their sweeps together
   // (C3, 10^6 columns: 62.9 -> 68.5e6 columns/s from 1 to 4 chunks per pipe and family).  Not below
-  // kMinChunkUnits column-units, which still fill the device twice over.
-  static constexpr size_t kMinChunkUnits = 16384;
+  // kMinChunkUnits column-units = one wave on every SIMD of the device for the one-lane kernels (256 CUs x 4 SIMDs
+  // x 64 lanes): smaller launches leave SIMDs idle and the step becomes a string of launch latencies.  Measured
+  // against the 16 384 of rounds 2-3: C2 (10^5 two-layer columns) 3.6e8 -> 6.8e8 columns/s, C3 with 2 10^5 columns
+  // 5.3e7 -> 6.4e7, the 10^6-column workloads unchanged (gpurun_out/r4z_min_chunk.txt -> profiles/).
+  static constexpr size_t kMinChunkUnits = 65536;
+  size_t min_chunk_units = kMinChunkUnits;     // env SPARTACUS_MIN_CHUNK_UNITS
   size_t chunk_columns(const ColumnClass& c, bool lw, int nspec) const {
     const size_t per_col = (size_t)nspec * c.maxlay * sizeof(double)
                            * (lay_nelem(lw, c.key) + col_nelem(lw, c.key) + eig_nelem(c.key));
@@ -644,7 +649,7 @@ class Plan {
       // (counted for the default number of pipes, so that the chunk size - and with it the size of the
       // scratch buffers - does not depend on set_pipes())
       const size_t parts = (size_t)chunks_per_pipe * (size_t)kDefaultPipes;
-      const size_t floor_cols = (kMinChunkUnits + (size_t)nspec - 1) / (size_t)std::max(1, nspec);
+      const size_t floor_cols = (min_chunk_units + (size_t)nspec - 1) / (size_t)std::max(1, nspec);
       const size_t even = std::max(floor_cols, (c.cols.size() + parts - 1) / parts);
       chunk = std::min(chunk, (even + 63) / 64 * 64);
     }
