@@ -281,6 +281,10 @@ struct Launch {
   double* col;           // adding-method scratch, same tiling
   double* eig;           // eigen records of the cooperative eigen-solver (ss_eigen_coop.hpp), same tiling
   int eig_nelem;
+  // Dense list of the cooperative unit-layers of this launch (coop_list_push, ss_eigen_coop.hpp): [0] = their
+  // number, [1 + m] = (layer << 32) | column unit.  Zeroed before the first pass, filled by it, read by the factor,
+  // Jacobi and layer kernels of the orders 7..16; null: those kernels find their units by position.
+  unsigned long long* coop_list;
   // Per-layer inputs of the class, re-laid out once per upload in the tiling of the
   // scratch records (ss_pack.hpp): unit cu of this launch is unit pack_cu0 + cu of the pack
   const double* pack;

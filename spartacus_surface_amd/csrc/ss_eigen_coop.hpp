@@ -255,6 +255,40 @@ SS_HD int coop_eig_post(const double* A, const double* dscale, const double* rec
   return 0;
 }
 
+// ---- the dense list of cooperative units ----
+// In a vegetated-urban column set only part of the unit-layers are full problems (C3 with 4 streams: 60 %; the
+// layers without vegetation or without clear air are sub-problems of a smaller order, done by the first pass on
+// one lane).  Found by position, the cooperative units leave 40 % of the lanes of the factor, Jacobi and layer
+// kernels idle.  The first pass therefore appends every cooperative unit-layer to a list - one atomic per wave, the
+// units of a wave in lane order, so that neighbours in the list are neighbours in the record tiling and a
+// workgroup still reads whole 128-byte lines of the records - and those three kernels take problem m of the list.
+// Launch grids stay what they were (the count is only known on the device): waves beyond the list exit at once.
+SS_HD void coop_list_push(unsigned long long* list, bool coop, int jlay, int cu) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (!list) return;
+  const unsigned long long mask = __ballot(coop);
+  if (mask == 0ULL) return;
+  const int lane = (int)(threadIdx.x & 63u);
+  const int leader = __ffsll((long long)mask) - 1;
+  unsigned long long base = 0ULL;
+  if (lane == leader) base = atomicAdd(list, (unsigned long long)__popcll(mask));
+  base = __shfl(base, leader);
+  if (coop)
+    list[1ULL + base + (unsigned long long)__popcll(mask & ((1ULL << lane) - 1ULL))] =
+        ((unsigned long long)(unsigned)jlay << 32) | (unsigned long long)(unsigned)cu;
+#else
+  (void)list; (void)coop; (void)jlay; (void)cu;
+#endif
+}
+// problem m of the list -> (layer, column unit); false: beyond its end
+SS_HD bool coop_list_get(const unsigned long long* list, unsigned long long m, int& jlay, int& cu) {
+  if (m >= list[0]) return false;
+  const unsigned long long e = list[1ULL + m];
+  jlay = (int)(e >> 32);
+  cu = (int)(e & 0xffffffffULL);
+  return true;
+}
+
 // ---- the cooperative kernel body ----
 #if defined(__HIP_DEVICE_COMPILE__)
 // sum over the G lanes of a group (butterfly: every lane ends with the same bits)

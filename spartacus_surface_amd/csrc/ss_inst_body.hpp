@@ -77,11 +77,17 @@ __global__ void __launch_bounds__(kBlock, (STAGE == 1 && r16_layer(R * NS, LW)) 
 template <int N>
 __global__ void __launch_bounds__(kBlock, SS_EIG_COOP_WAVES) k_eig_coop(const Launch L) {
   constexpr int G = coop_lanes(N);
-  const int part = blockIdx.x % G, tl = blockIdx.x / G;
-  const int tile = tl / L.maxlay, jlay = tl % L.maxlay;
-  const int cu = tile * kBlock + part * (kBlock / G) + (int)threadIdx.x / G;
-  if (cu >= L.ncu) return;
-  if (jlay >= L.in.nlay[L.cols[cu / L.nspec]]) return;
+  int cu, jlay;
+  if (L.coop_list) {
+    if (!coop_list_get(L.coop_list, (unsigned long long)blockIdx.x * (kBlock / G) + threadIdx.x / G, jlay, cu)) return;
+  } else {
+    const int part = blockIdx.x % G, tl = blockIdx.x / G;
+    const int tile = tl / L.maxlay;
+    jlay = tl % L.maxlay;
+    cu = tile * kBlock + part * (kBlock / G) + (int)threadIdx.x / G;
+    if (cu >= L.ncu) return;
+    if (jlay >= L.in.nlay[L.cols[cu / L.nspec]]) return;
+  }
   if constexpr (coop_order(N))
     coop_eig_unit<N, G>(L.eig + rec_base(jlay, L.maxlay, EigRec<N>::NELEM, cu), kRecStride, (int)threadIdx.x % G,
                         L.eigen_fail ? L.eigen_fail + kSlotOneLaneUnits : nullptr, L.cfg.decline_cooperative == 2);
@@ -106,11 +112,17 @@ template <bool U, int R, int NS, bool LW>
 __global__ void __launch_bounds__(kBlock16, 2) k_pre16(const Launch L) {
   constexpr int N = R * NS;
   constexpr int UPB = kUnits16;
-  const int part = blockIdx.x % kParts16, tl = blockIdx.x / kParts16;
-  const int tile = tl / L.maxlay, jlay = tl % L.maxlay;
-  const int cu = tile * kBlock + part * UPB + (int)threadIdx.x / r16::kRow;
-  if (cu >= L.ncu) return;
-  if (jlay >= L.in.nlay[L.cols[cu / L.nspec]]) return;
+  int cu, jlay;
+  if (L.coop_list) {
+    if (!coop_list_get(L.coop_list, (unsigned long long)blockIdx.x * UPB + threadIdx.x / r16::kRow, jlay, cu)) return;
+  } else {
+    const int part = blockIdx.x % kParts16, tl = blockIdx.x / kParts16;
+    const int tile = tl / L.maxlay;
+    jlay = tl % L.maxlay;
+    cu = tile * kBlock + part * UPB + (int)threadIdx.x / r16::kRow;
+    if (cu >= L.ncu) return;
+    if (jlay >= L.in.nlay[L.cols[cu / L.nspec]]) return;
+  }
   if constexpr (coop_order(N)) {
     double* erec = L.eig + rec_base(jlay, L.maxlay, EigRec<N>::NELEM, cu);
     if (!(rec_elem_load(erec, kRecStride, EigRec<N>::STATUS) > 0.5)) return;     // same for the whole row
@@ -123,11 +135,17 @@ __global__ void __launch_bounds__(kBlock16, 2) k_pre16(const Launch L) {
 template <int N, int D, bool LW>
 __global__ void __launch_bounds__(kBlock16, 2) k_layer16(const Launch L) {
   constexpr int UPB = kUnits16;
-  const int part = blockIdx.x % kParts16, tl = blockIdx.x / kParts16;
-  const int tile = tl / L.maxlay, jlay = tl % L.maxlay;
-  const int cu = tile * kBlock + part * UPB + (int)threadIdx.x / r16::kRow;
-  if (cu >= L.ncu) return;
-  if (jlay >= L.in.nlay[L.cols[cu / L.nspec]]) return;
+  int cu, jlay;
+  if (L.coop_list) {
+    if (!coop_list_get(L.coop_list, (unsigned long long)blockIdx.x * UPB + threadIdx.x / r16::kRow, jlay, cu)) return;
+  } else {
+    const int part = blockIdx.x % kParts16, tl = blockIdx.x / kParts16;
+    const int tile = tl / L.maxlay;
+    jlay = tl % L.maxlay;
+    cu = tile * kBlock + part * UPB + (int)threadIdx.x / r16::kRow;
+    if (cu >= L.ncu) return;
+    if (jlay >= L.in.nlay[L.cols[cu / L.nspec]]) return;
+  }
   if constexpr (r16_layer(N, LW)) {
     const double* erec = L.eig + rec_base(jlay, L.maxlay, EigRec<N>::NELEM, cu);
     if (!(rec_elem_load(erec, kRecStride, EigRec<N>::STATUS) > 0.5)) return;     // same for the whole row
@@ -254,6 +272,7 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev, hipStream_t f
   if constexpr (coop_order(SS_INST_NREG * NS)) {
     // W of every full problem -> cooperative Jacobi -> layer matrices with the eigen-decomposition from the record
     if (L.eig_nelem != EigRec<SS_INST_NREG * NS>::NELEM || !L.eig) return kLaunchBadRecord;
+    if (L.coop_list) SS_TRY(hipMemsetAsync(L.coop_list, 0, sizeof(unsigned long long), stream));
     hipLaunchKernelGGL((k_layer<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0, 1>), glayer, dim3(kBlock), 0,
                        stream, L);
     SS_TRY(hipGetLastError());

@@ -191,6 +191,8 @@ class Plan {
   double* d_lay[kMaxPipes] = {};
   double* d_col[kMaxPipes] = {};
   double* d_eig[kMaxPipes] = {};
+  size_t coop_list_bytes = 0;      // tail of every eigen buffer: the dense list of cooperative unit-layers
+  bool use_coop_list = true;       // env SPARTACUS_NO_COOP_LIST=1: the kernels find their units by position
   size_t scratch_budget_bytes = 0;
   static constexpr int kDefaultPipes = 4;
   int pipes_wanted = kDefaultPipes;
@@ -224,6 +226,7 @@ class Plan {
       d_lay[p] = d_col[p] = d_eig[p] = nullptr;
     }
     lay_bytes = col_bytes = eig_bytes = 0;
+    coop_list_bytes = 0;
     if (d_eigen_fail) be.free(d_eigen_fail);
     d_index = nullptr; d_eigen_fail = nullptr;
     timers.release();
@@ -367,6 +370,7 @@ class Plan {
     want_profiles = profiles != 0;
     const char* mb = std::getenv("SPARTACUS_SCRATCH_MB");
     scratch_budget_bytes = (mb ? (size_t)std::atol(mb) : (size_t)4096) << 20;
+    if (const char* ncl = std::getenv("SPARTACUS_NO_COOP_LIST")) use_coop_list = !(ncl[0] == '1');
     if (const char* mcu = std::getenv("SPARTACUS_MIN_CHUNK_UNITS")) min_chunk_units = (size_t)std::max(64L, std::atol(mcu));
     const char* cpp = std::getenv("SPARTACUS_CHUNKS_PER_PIPE");
     chunks_per_pipe = cpp ? std::max(0, std::atoi(cpp)) : 4;
@@ -572,7 +576,7 @@ class Plan {
     be.h2d_staged(d_index, idx.data(), idx.size() * sizeof(int32_t));
 
     // scratch sizing: the largest per-column need over all classes
-    size_t need_lay = 0, need_col = 0, need_eig = 0;
+    size_t need_lay = 0, need_col = 0, need_eig = 0, need_list = 0;
     auto account = [&](const std::vector<ColumnClass>& cls, bool lw, int nspec) {
       for (auto& c : cls) {
         const size_t per_unit = (size_t)c.maxlay * sizeof(double);
@@ -581,10 +585,14 @@ class Plan {
         need_lay = std::max(need_lay, units * per_unit * lay_nelem(lw, c.key));
         need_col = std::max(need_col, units * per_unit * col_nelem(lw, c.key));
         need_eig = std::max(need_eig, units * per_unit * eig_nelem(c.key));
+        // (the dense list of cooperative unit-layers, at the END of the eigen buffer of a pipe: Launch::coop_list)
+        if (eig_nelem(c.key)) need_list = std::max(need_list, ((units * (size_t)c.maxlay + 8) * sizeof(unsigned long long) + 255) / 256 * 256);
       }
     };
     account(sw_classes, false, nsw);
     account(lw_classes, true, nlw);
+    coop_list_bytes = std::max(coop_list_bytes, need_list);
+    if (need_eig) need_eig += coop_list_bytes;
     // a second pipe only pays off when there is more than one launch to overlap
     size_t nlaunch = 0;
     for (auto& c : sw_classes) nlaunch += (c.cols.size() + chunk_columns(c, false, nsw) - 1) / chunk_columns(c, false, nsw);
@@ -771,6 +779,9 @@ class Plan {
     L.col = d_col[pipe];
     L.eig = d_eig[pipe];
     L.eig_nelem = eig_nelem(c.key);
+    L.coop_list = (L.eig_nelem && d_eig[pipe] && coop_list_bytes && use_coop_list)
+                      ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(d_eig[pipe]) + (eig_bytes - coop_list_bytes))
+                      : nullptr;
     L.pack = c.d_pack;
     L.pack_maxlay = c.maxlay;
     L.pack_cu0 = (int)(first * (size_t)L.nspec);

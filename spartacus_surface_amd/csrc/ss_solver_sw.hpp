@@ -267,6 +267,7 @@ SS_HD void layer_first_sw(const Launch& L, int cu, int jlay, const W& w) {
   if (ierr != 0 && L.eigen_fail) *L.eigen_fail += 1ULL;
 #endif
   rec_elem_store(erec, st, ER::STATUS, status);
+  coop_list_push(L.coop_list, status > 0.5, jlay, cu);
   if (status == 0.0 && L.eigen_fail) {
 #if defined(__HIP_DEVICE_COMPILE__)
     atomicAdd(L.eigen_fail + kSlotOneLaneUnits, 1ULL);
