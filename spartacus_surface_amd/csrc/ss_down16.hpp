@@ -108,7 +108,14 @@ SS_HD void column_down_lw(const Launch& L, int cu) {
   const double top_emissivity = L.top1[cidx], top_emission = L.top2[cidx];
   double* const* FA = L.flux_a.f;     // lw_internal (pass 0)
   double* const* FB = L.flux_b.f;     // lw_norm     (pass 1)
+// (the member pointers of the two flux objects are read from the kernel-argument segment where they are used:
+// held from the kernel entry they are 108 scalar registers, spilled lane by lane into VGPRs - SS_LAUNCH_HERE)
+#if !defined(SS_DOWN16_POINTERS_AT_ENTRY)
+#define PUT2(F, idx, v0, v1) do { if (lane0()) { SS_LAUNCH_HERE(L, Lo_); double* a_ = Lo_.flux_a.f[F]; double* b_ = Lo_.flux_b.f[F]; \
+    if (a_) a_[idx] = (v0); if (b_) b_[idx] = (v1); } } while (0)
+#else
 #define PUT2(F, idx, v0, v1) do { if (lane0()) { if (FA[F]) FA[F][idx] = (v0); if (FB[F]) FB[F][idx] = (v1); } } while (0)
+#endif
 
   rv dn_above[2] = {rv(0.0), select(g.rg[0], g.hw, rv(0.0))}, up_above[2] = {0.0, 0.0};
   PUT2(F_TOP_DN, cidx, 0.0, 1.0);
@@ -387,7 +394,14 @@ SS_HD void column_down_sw(const Launch& L, int cu) {
   const rv hw_r = select(lane_lt(NS), g.hw, rv(0.0));
   double* const* FA = L.flux_a.f;     // sw_norm_dir  (pass 0)
   double* const* FB = L.flux_b.f;     // sw_norm_diff (pass 1)
+// (the member pointers of the two flux objects are read from the kernel-argument segment where they are used:
+// held from the kernel entry they are 108 scalar registers, spilled lane by lane into VGPRs - SS_LAUNCH_HERE)
+#if !defined(SS_DOWN16_POINTERS_AT_ENTRY)
+#define PUT2(F, idx, v0, v1) do { if (lane0()) { SS_LAUNCH_HERE(L, Lo_); double* a_ = Lo_.flux_a.f[F]; double* b_ = Lo_.flux_b.f[F]; \
+    if (a_) a_[idx] = (v0); if (b_) b_[idx] = (v1); } } while (0)
+#else
 #define PUT2(F, idx, v0, v1) do { if (lane0()) { if (FA[F]) FA[F][idx] = (v0); if (FB[F]) FB[F][idx] = (v1); } } while (0)
+#endif
 
   double dir_above[D];
   dir_above[0] = 1.0 / cos_sza;
