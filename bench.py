@@ -252,6 +252,12 @@ def roofline_block(fam_ms, fam_n, nsteps, columns, case, pmc, evidence, ms_per_s
           "serial_ms_per_step_all_kernels": sum(fam_ms.values()) / nsteps,
           "peak_note": "fp64 vector = fp64 matrix peak of MI355X; the kernels are scalar-per-lane fp64 FMA code "
                        "(6 x 6 problems, one per lane): MFMA does not apply (DESIGN.md section 3)",
+          # what this chip SUSTAINS on streams of independent v_fma_f64 (tools/experiments/issue_probe.hip,
+          # profiles/round4_issue_probe.txt; context for "frac", which stays priced against the nominal peak):
+          # one wave per SIMD - what 512-register kernels like these run at - issues ANY instruction,
+          # scalar ones included, every ~4.8 cycles of a clock that sits at ~2.2 GHz under this load
+          "sustained_fma_only_TFLOPs": {"1_wave_per_simd": 42.1, "2": 62.7, "4": 65.1, "8": 69.3,
+                                        "source": "profiles/round4_issue_probe.txt"},
           "hbm": {"algorithmic_bytes_per_column": bpc, "of": "%s inputs + outputs only" % spectral.upper(),
                   "achieved": hbm_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_ach / HBM_PEAK_GBS,
                   "note": "intensity ~%.0f flop per algorithmic byte of the whole step: the path cannot be "
