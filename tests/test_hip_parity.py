@@ -446,6 +446,38 @@ def test_pipes_and_chunking_do_not_change_results(monkeypatch):
             assert np.array_equal(v, other[k]), (pipes, mb, k)
 
 
+def test_coop_list_and_chunk_floor_do_not_change_results(monkeypatch):
+    """Orders 7..16: the factor, Jacobi and layer kernels take their units from the dense list the first pass
+    writes (default) or find them by position (SPARTACUS_NO_COOP_LIST=1); chunks are cut with a floor of 65 536
+    column-units (default) or a smaller one (SPARTACUS_MIN_CHUNK_UNITS).  Neither is visible in the results:
+    bit-identical outputs, on a column set with mixed tile kinds (cooperative and one-lane units in every wave)."""
+    from oracle import checker
+    from spartacus_surface_amd import workloads
+    radsurf = _hip()
+    case = workloads.c4_mixed(ncol=1500, seed=77, nsw=2, nlw=2, nstream=4)
+    cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
+
+    def run(env):
+        for k in ("SPARTACUS_NO_COOP_LIST", "SPARTACUS_MIN_CHUNK_UNITS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        plan = radsurf.Plan(cfg, cp, sw, lw, want_profiles=True)
+        plan.solve()
+        out = checker.alloc_outputs(cfg, cp, True)
+        plan.download(out["bc_out"], out["sw_norm_dir"], out["sw_norm_diff"], out["lw_internal"],
+                      out["lw_norm"])
+        plan.close()
+        return fixture_io.flatten_outputs(out)
+
+    base = run({})
+    for env in ({"SPARTACUS_NO_COOP_LIST": "1"}, {"SPARTACUS_MIN_CHUNK_UNITS": "512"},
+                {"SPARTACUS_MIN_CHUNK_UNITS": "512", "SPARTACUS_NO_COOP_LIST": "1"}):
+        other = run(env)
+        for k, v in base.items():
+            assert np.array_equal(v, other[k]), (env, k)
+
+
 def _host_entry(radsurf, case, out, i0=1, i1=None):
     cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
     radsurf.radsurf(cfg, cp, sw, lw, out["bc_out"], i0, cp.ncol if i1 is None else i1, out["sw_norm_dir"],

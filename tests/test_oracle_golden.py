@@ -43,3 +43,37 @@ def test_golden_set_is_complete():
     for fam in ("simple__", "rami4pilps__", "urban__", "rami5__", "single_layer__"):
         assert any(n.startswith(fam) for n in names), fam
     assert len(names) >= 45
+
+
+@pytest.mark.parametrize("name", ["simple__test_surfaces", "simple__test_overhang"])
+def test_limit_yardstick_of_the_degenerate_layer(name, checkers):
+    """The second singular point of the reference's algorithm (tests/golden/make_golden.py: DEGENERATE_LIMIT):
+    a vegetated layer whose vegetation has an extinction of exactly zero.  Pins what the fixtures store and why:
+    (i) the stored truth IS the binary128 evaluation with 1e-15 in place of the zeros, (ii) it does not depend
+    on that number (1e-12 gives the same to 1e-9: a limit), (iii) the binary128 evaluation AT zero is farther from
+    it than the fp64 reference is - the reason it cannot serve as the yardstick there."""
+    import copy
+    path = [p for p in golden_files() if os.path.basename(p)[:-4] == name][0]
+    case, expected = fixture_io.load_case(path)
+    cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
+
+    def quad(eps):
+        c = copy.deepcopy(cp)
+        ve, vf = np.asarray(cp.veg_ext, dtype=np.float64), np.asarray(cp.veg_fraction, dtype=np.float64)
+        assert ((ve == 0.0) & (vf > 0.0)).any()
+        if eps is not None:
+            c.veg_ext = np.where((ve == 0.0) & (vf > 0.0), eps, ve)
+        out, _ = checkers.run_oracle(cfg, c, sw, lw, want_profiles=case["want_profiles"], quad=True,
+                                     do_simple_spectrum=case["do_simple_spectrum"])
+        return fixture_io.flatten_outputs(out)
+
+    truth = case["ref_truth"]
+    k = "lw_norm.veg_air_abs"
+    assert k in truth
+    lim15, lim12, at0 = quad(1.0e-15), quad(1.0e-12), quad(None)
+    scale = np.max(np.abs(expected[k]))
+    assert np.max(np.abs(lim15[k] - truth[k])) <= 1.0e-13 * scale
+    assert np.max(np.abs(lim12[k] - lim15[k])) <= 1.0e-9 * scale
+    ref_off = np.max(np.abs(expected[k] - truth[k])) / scale
+    jump = np.max(np.abs(at0[k] - truth[k])) / scale
+    assert jump > 3.0 * ref_off > 3.0e-5, (jump, ref_off)
