@@ -212,7 +212,30 @@ struct Cfg {
   // cooperative route and takes the second pass of the layer kernel (one lane, general eigen-solver) -
   // the path of units without the symmetric structure, which well-formed inputs hardly ever reach
   int decline_cooperative;              // (2: the cooperative route runs and is then treated as not converged)
+  // diagnostic (env SPARTACUS_DECLINE_SYM=1): every unit of the orders 3..6 is declined by the symmetrised route and
+  // takes the out-of-line general route (layer_unit_sw_cold / layer_unit_lw_cold) - the path of units whose matrices
+  // are not positive definite, which no input of the reference's test-suite reaches
+  int decline_symmetric;
 };
+
+#if defined(SS_NO_DECLINE_SYM_SWITCH)      // (experiment builds: what the diagnostic switch costs the hot path)
+#define SS_DECLINE_SYM(L) false
+#else
+#define SS_DECLINE_SYM(L) ((L).cfg.decline_symmetric != 0)
+#endif
+
+// The launch descriptor of the running kernel for an OUT-OF-LINE callee.  Every kernel of the solver takes the
+// descriptor as its only argument, by value, so it IS the kernel-argument segment.  The pointer has to be formed in
+// the kernel (after inlining, that is where this is called): inside a callee __builtin_amdgcn_kernarg_segment_ptr()
+// folds to NULL - the implicit argument is not passed on - and the callee reads its descriptor from address 0
+// ("Memory access fault ... on address (nil)": what the cold routes did from round 3 until an edge-input sweep
+// reached them in round 4).  Handing the callee &L of a by-value kernel argument instead makes every wave copy the
+// 800-byte descriptor to scratch at kernel entry (measured in round 3: the write traffic of the layer kernel doubled).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SS_LAUNCH_PTR_FOR_CALLEE(L) ((const ::ss::Launch*)__builtin_amdgcn_kernarg_segment_ptr())
+#else
+#define SS_LAUNCH_PTR_FOR_CALLEE(L) (&(L))
+#endif
 
 // canopy_flux_type members by index (order of radsurf_canopy_flux.F90:27-91,
 // = order of ss_flux in the C-ABI header)

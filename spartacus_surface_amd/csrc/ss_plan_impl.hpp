@@ -767,6 +767,8 @@ class Plan {
     {
       const char* e = std::getenv("SPARTACUS_DECLINE_COOP");
       L.cfg.decline_cooperative = (e && e[0] == '1') ? 1 : (e && e[0] == '2') ? 2 : 0;
+      const char* ds = std::getenv("SPARTACUS_DECLINE_SYM");
+      L.cfg.decline_symmetric = (ds && ds[0] == '1') ? 1 : 0;
     }
     L.cols = d_index + c.dev_offset + first;
     L.ncols = (int)count;

@@ -166,13 +166,13 @@ SS_HD bool gamma_structure_ok(const double* frac, const double* fx);
 template <int NF, int DF, int N, int D, int I0, int R0, bool GENERAL, class W>
 SS_HD int calc_matrices_sw_route(const double* g0, const double* g1, const double* g2, const double* g3,
                                  const double* dsc0, const double* dsc, double dz, const W& w,
-                                 const CoopEig* coop = nullptr) {
+                                 const CoopEig* coop = nullptr, bool decline_sym = false) {
 #if !defined(SS_NO_SYM_LAYER)
   // the register-resident orders, and (rolled loops, matrices in scratch) the orders above those of the
   // row-of-16 kernels: 3 regions x 8 streams = 24 - the general eigen-solver then only sees declined units
   if constexpr (!GENERAL && NF >= 3 && (N <= SS_UNROLL_MAX || sym_scratch_order(N))) {
     int rc = -1;
-    if (dsc) {
+    if (dsc && !(decline_sym && NF <= SS_UNROLL_MAX)) {
       if constexpr (N <= SS_UNROLL_MAX) rc = sym::calc_matrices_sw_sym<NF, DF, N, D, I0, R0>(g0, g1, g2, g3, dsc0, dsc, dz, w, w.scratch());
       else rc = sym::calc_matrices_sw_sym<NF, DF, N, D, I0, R0>(g0, g1, g2, g3, dsc0, dsc, dz, w, LaneLds<false>{});
     }
@@ -506,7 +506,7 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
     get_block<N, NS, NS, 0, 0>(g1, s1);
     get_block<N, NS, NS, 0, 0>(g2, s2);
     get_block<N, NS, 1, 0, 0>(g3, s3);
-    ierr = calc_matrices_sw_route<N, D, NS, 1, 0, 0, GENERAL>(s0, s1, s2, s3, dsc0, dsc, g.dz, w);
+    ierr = calc_matrices_sw_route<N, D, NS, 1, 0, 0, GENERAL>(s0, s1, s2, s3, dsc0, dsc, g.dz, w, nullptr, SS_DECLINE_SYM(L));
   } else if (STAGE != 1 && frac[0] <= L.cfg.min_vegetation_fraction) {
     // vegetated regions only: (ns+1:n, 2:nreg)
     constexpr int NV = (NREG > 1) ? (NREG - 1) * NS : NS;
@@ -519,13 +519,13 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
       get_block<N, NV, NV, IV, IV>(g1, s1);
       get_block<N, NV, NV, IV, IV>(g2, s2);
       get_block<N, NV, DV, IV, RV>(g3, s3);
-      ierr = calc_matrices_sw_route<N, D, NV, DV, IV, RV, GENERAL>(s0, s1, s2, s3, dsc0 + RV, dsc + IV, g.dz, w);
+      ierr = calc_matrices_sw_route<N, D, NV, DV, IV, RV, GENERAL>(s0, s1, s2, s3, dsc0 + RV, dsc + IV, g.dz, w, nullptr, SS_DECLINE_SYM(L));
     } else {
       ierr = 0;
     }
   } else {
     if constexpr (STAGE == 1) ierr = 0;     // (full problems of the first pass went the cooperative way above)
-    else ierr = calc_matrices_sw_route<N, D, N, D, 0, 0, GENERAL>(g0, g1, g2, g3, dsc0, dsc, g.dz, w, STAGE == 2 ? &ce : nullptr);
+    else ierr = calc_matrices_sw_route<N, D, N, D, 0, 0, GENERAL>(g0, g1, g2, g3, dsc0, dsc, g.dz, w, STAGE == 2 ? &ce : nullptr, SS_DECLINE_SYM(L));
   }
   if constexpr (!GENERAL && STAGE == 0 && N <= SS_UNROLL_MAX) {
     if (ierr < 0) {
@@ -534,13 +534,8 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
       using LRec = SwLayRec<N, D>;       // what the pipeline reads
       double rec[FRec::NELEM];
       for (int k = 0; k < FRec::NELEM; ++k) rec[k] = 0.0;
-      // (device: the cold unit finds the launch descriptor in the kernel-argument segment itself; handing it
-      // &L would make every wave copy the descriptor - 800 bytes per lane - to scratch at kernel entry)
-#if defined(__HIP_DEVICE_COMPILE__)
-      layer_unit_sw_cold<URBAN, NREG, NS>(nullptr, cu, jlay, rec);
-#else
-      layer_unit_sw_cold<URBAN, NREG, NS>(&L, cu, jlay, rec);
-#endif
+      // (device: the cold unit is handed the kernel-argument segment, which is the descriptor: ss_common.hpp)
+      layer_unit_sw_cold<URBAN, NREG, NS>(SS_LAUNCH_PTR_FOR_CALLEE(L), cu, jlay, rec);
       if constexpr (LRec::PACKED) {
         // R^ = D^-1 R D, T^ likewise: lower triangles (reciprocity makes them symmetric)
         double rdv[N];
@@ -575,13 +570,8 @@ SS_HD void layer_unit_sw(const Launch& L, int cu, int jlay, const W& w) {
 
 template <bool URBAN, int NREG, int NS>
 SS_HD_NOINLINE void layer_unit_sw_cold(const Launch* Lp, int cu, int jlay, double* rec) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  // every kernel that reaches this unit takes the launch descriptor as its only argument, by value
-  (void)Lp;
-  const Launch& L = *(const Launch*)__builtin_amdgcn_kernarg_segment_ptr();
-#else
+  // (Lp: the kernel-argument segment = the descriptor, formed by the caller IN the kernel: SS_LAUNCH_PTR_FOR_CALLEE)
   const Launch& L = *Lp;
-#endif
   const ArrayRecWriter w{rec, nullptr};
   layer_unit_sw<URBAN, NREG, NS, ArrayRecWriter, 0, true>(L, cu, jlay, w);
 }

@@ -152,6 +152,34 @@ def test_golden_host_entry_chunk_pipeline(name, monkeypatch):
     assert not bad, "outside the parity bar: %s" % bad[:5]
 
 
+@pytest.mark.parametrize("name", ["simple__test_surfaces", "simple__test_closed", "urban__2stream", "urban__1stream",
+                                  "extra__ragged-tiles", "extra__urban-3stream", "rami4pilps__vis-med-0.3"])
+def test_golden_with_symmetric_route_declined(name, monkeypatch):
+    """Orders 3..6: a unit whose scaled matrices are not positive definite (a single-scattering albedo of exactly 1 in
+    the longwave next to vegetation of zero extinction, say) is declined by the symmetrised route and computed again by
+    the general route in an OUT-OF-LINE unit of the fused kernels (layer_unit_sw_cold / layer_unit_lw_cold).  No input
+    of the reference's test-suite reaches that unit, and from round 3 until the edge-input sweep of round 4
+    (tools/fuzz_parity.py --edge) it read its launch descriptor from address 0 on the device
+    (csrc/ss_common.hpp: SS_LAUNCH_PTR_FOR_CALLEE).  SPARTACUS_DECLINE_SYM=1 sends EVERY unit there: same goldens,
+    same bar.  (Not simple__test_overhang: at its degenerate layer the general route - eigenvector matrices inverted
+    as the reference does - has the reference's kind of error, 3.8e-5 from the limit against the reference's 2.6e-5,
+    1.1 x the element-wise bar; the symmetrised route is 6e-13 from it.)"""
+    radsurf = _hip()
+    have = [p for p in golden_files() if os.path.basename(p)[:-4] == name]
+    if not have:
+        pytest.skip("fixture not present")
+    monkeypatch.setenv("SPARTACUS_DECLINE_SYM", "1")
+    case, expected = fixture_io.load_case(have[0])
+    cfg, cp, sw, lw = case["config"], case["canopy"], case["sw"], case["lw"]
+    out = _alloc(case)
+    radsurf.radsurf(cfg, cp, sw, lw, out["bc_out"], 1, cp.ncol, out["sw_norm_dir"],
+                    out["sw_norm_diff"], out["lw_internal"], out["lw_norm"])
+    got = fixture_io.flatten_outputs(out)
+    bad = fixture_io.parity_violations(got, expected, dict(case["ref_noise"]), truth=case["ref_truth"],
+                                       noise_arr=case["ref_noise_arr"])
+    assert not bad, "outside the parity bar: %s" % bad[:5]
+
+
 @pytest.mark.parametrize("how", ["1", "2"])
 @pytest.mark.parametrize("name", ["urban__4stream", "rami5__HET07_JPS_SUM-56-direct", "rami4pilps__vis-snw-0.3-2-4",
                                   "extra__urban-5stream"])
