@@ -145,3 +145,22 @@ def test_alternative_kernel_forms_agree(flag, what, tmp_path):
             else:
                 den = np.maximum(np.abs(a[k]), 1.0e-3 * max(1.0e-300, float(np.max(np.abs(a[k])))) if a[k].size else 1.0)
                 assert np.all(np.abs(a[k] - b[k]) <= what * den), (n, k)
+
+
+@pytest.mark.parametrize("name", ["simple__test_surfaces", "urban__2stream", "extra__ragged-tiles"])
+def test_emulated_general_route_of_declined_units(emul, name, monkeypatch):
+    """SPARTACUS_DECLINE_SYM=1: every unit of the orders 3..6 is declined by the symmetrised route and recomputed by
+    the out-of-line general route of the layer units (layer_unit_sw_cold / layer_unit_lw_cold), then replayed through
+    the fused kernels' writers - the path of units whose matrices are not positive definite, which no input of the
+    reference's test-suite takes (on the device: tests/test_hip_parity.py::test_golden_with_symmetric_route_declined)."""
+    have = {os.path.basename(p)[:-4]: p for p in golden_files()}
+    if name not in have:
+        pytest.skip("fixture not present")
+    monkeypatch.setenv("SPARTACUS_DECLINE_SYM", "1")
+    case, expected = fixture_io.load_case(have[name])
+    out, nfail = emul.run_emul(case["config"], case["canopy"], case["sw"], case["lw"], want_profiles=case["want_profiles"],
+                               do_simple_spectrum=case["do_simple_spectrum"])
+    assert nfail == 0
+    bad = fixture_io.parity_violations(fixture_io.flatten_outputs(out), expected, dict(case["ref_noise"]),
+                                       truth=case["ref_truth"], noise_arr=case["ref_noise_arr"], slack=2.0)
+    assert not bad, "outside the parity bar: %s" % bad[:5]
