@@ -132,8 +132,9 @@ __global__ void __launch_bounds__(kBlock16, 2) k_pre16(const Launch L) {
 
 // layer matrices of the cooperative units on the 16 lanes of a DPP row (ss_layer16.hpp):
 // block -> (tile of 64 units, layer, sixteenth of the tile); 4 units per wave
-template <int N, int D, bool LW>
+template <bool U, int R, int NS, bool LW>
 __global__ void __launch_bounds__(kBlock16, 2) k_layer16(const Launch L) {
+  constexpr int N = R * NS, D = R;
   constexpr int UPB = kUnits16;
   int cu, jlay;
   if (L.coop_list) {
@@ -149,10 +150,11 @@ __global__ void __launch_bounds__(kBlock16, 2) k_layer16(const Launch L) {
   if constexpr (r16_layer(N, LW)) {
     const double* erec = L.eig + rec_base(jlay, L.maxlay, EigRec<N>::NELEM, cu);
     if (!(rec_elem_load(erec, kRecStride, EigRec<N>::STATUS) > 0.5)) return;     // same for the whole row
+    const r16::EigenvectorsFromScalars<U, R, NS, LW> load_ev{&L.lg};
     if constexpr (LW)
-      r16::layer_lw<N>(erec, kRecStride, L.lay + rec_base(jlay, L.maxlay, LwRec<N>::NELEM, cu));
+      r16::layer_lw<N>(erec, kRecStride, L.lay + rec_base(jlay, L.maxlay, LwRec<N>::NELEM, cu), load_ev);
     else
-      r16::layer_sw<N, D>(erec, kRecStride, L.lay + rec_base(jlay, L.maxlay, SwRec<N, D>::NELEM, cu));
+      r16::layer_sw<N, D>(erec, kRecStride, L.lay + rec_base(jlay, L.maxlay, SwRec<N, D>::NELEM, cu), load_ev);
   }
 }
 
@@ -283,7 +285,7 @@ int launch_ns(const Launch& L, hipStream_t stream, hipEvent_t* ev, hipStream_t f
     hipLaunchKernelGGL((k_eig_coop<SS_INST_NREG * NS>), dim3(gx * (unsigned)L.maxlay * coop_lanes(SS_INST_NREG * NS)), dim3(kBlock), 0, stream, L);
     SS_TRY(hipGetLastError());
     if constexpr (r16_layer(SS_INST_NREG * NS, SS_INST_LW != 0)) {
-      hipLaunchKernelGGL((k_layer16<SS_INST_NREG * NS, SS_INST_NREG, SS_INST_LW != 0>), dim3(gx * (unsigned)L.maxlay * kParts16),
+      hipLaunchKernelGGL((k_layer16<SS_INST_URBAN, SS_INST_NREG, NS, SS_INST_LW != 0>), dim3(gx * (unsigned)L.maxlay * kParts16),
                          dim3(kBlock16), 0, stream, L);
       SS_TRY(hipGetLastError());
     }

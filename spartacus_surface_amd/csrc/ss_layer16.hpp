@@ -258,33 +258,64 @@ SS_HD bool cholesky_rows(rv* A, rv* Lr, double* rs, double thr) {
 // is D F^-T F^-1 D^-1 b - two substitutions with the factor that is at hand here, where the layer kernel
 // used to factorise G1 + G2.
 // (E = own row of G1 - G2, g2 = own row of G2; both are consumed)
-template <int N, bool LW>
+// The scaled matrices C = -D^-1 (G1 - G2) D and M = C - 2 D^-1 G2 D (own rows; rows beyond the order zero), the scale
+// of the pivot test and d = the scaling on every lane, rd = the own reciprocal.  (E = own row of G1 - G2, g2 of G2)
+template <int N>
+SS_HD void scaled_CM(const rv& dsc, const rv* E, const rv* g2, rv* C, rv* M, double& size, rv& rd) {
+  double d[N];
+  all_of<N>(dsc, d);
+  rd = select(lane_lt(N), 1.0 / (dsc + select(lane_lt(N), rv(0.0), rv(1.0))), rv(0.0));
+  size = 0.0;             // scale of the pivot test: the largest element of the scaled matrices
+  rv big = 0.0;           // largest |element| of the two scaled matrices in the own row
+  SS_UNROLL_FULL
+  for (int j = 0; j < N; ++j) {
+    const rv sc = rd * d[j];
+    const rv sj = g2[j] * sc;
+    C[j] = -(E[j] * sc);
+    M[j] = C[j] - 2.0 * sj;
+    big = r_max(big, r_max(r_abs(C[j]), r_abs(sj)));
+  }
+  static_for<0, N>([&](auto kc) { size = ss_max(size, bc<decltype(kc)::value>(big)); });
+  // rows beyond the order: identity (their pivots are never used, but keep the arithmetic finite)
+  SS_UNROLL_FULL
+  for (int j = 0; j < N; ++j) {
+    C[j] = select(lane_lt(N), C[j], rv(0.0));
+    M[j] = select(lane_lt(N), M[j], rv(0.0));
+  }
+}
+// Own rows of D L and of -D L^-T from the factorisation of C by cholesky_rows (C: what it left of the matrix -
+// the own row of L^T scaled by the own pivot root; L: the own row of the factor; rsL: the reciprocal pivot roots)
+template <int N>
+SS_HD void factor_rows(const rv& dsc, const rv* C, const rv* L, const double* rsL, rv* DL, rv* AX) {
+  const rv rsL_own = own<N>(rsL);
+  SS_UNROLL_FULL
+  for (int j = 0; j < N; ++j) DL[j] = L[j] * dsc;
+  // -D L^-T: R = L^T is upper triangular with its rows on the lanes; R X = I by back substitution
+  SS_UNROLL_FULL
+  for (int j = 0; j < N; ++j) AX[j] = select(lane_eq(j), rv(1.0), rv(0.0));
+  static_for_down<1, N>([&](auto kc) {
+    constexpr int K = decltype(kc)::value;
+    // R(i, K) = C[K] * rsL_own for i <= K; x_K = (row K of X) / R(K, K) = (row K) * rsL[K]
+    const rv u = select(lane_lt(K), (C[K] * rsL_own) * rsL[K], rv(0.0));
+    row_fma<K, N>(AX, AX, -u);
+  });
+  const rv sc = -(dsc * rsL_own);
+  SS_UNROLL_FULL
+  for (int j = 0; j < N; ++j) AX[j] = AX[j] * sc;
+}
+
+// STORE_FACTORS: D L and -D L^-T go to the record (the kernel-level entries, whose layer step reads them back);
+// the solver's layer kernel recomputes them from the layer's scalars instead (load_eigenvectors_scalars): k_pre16 is
+// bound by its writes and k_layer16 by its 8-byte record reads, and a Cholesky factorisation on the lanes costs
+// neither of them anything.
+template <int N, bool LW, bool STORE_FACTORS = true>
 SS_HD void eig_pre_rows(double* erec, long stride, const rv* E, const rv* g2, unsigned long long* one_lane_units) {
   using ER = EigRec<N>;
   const rv dsc = load_vec<N>(erec, stride, ER::VEC);
-  double d[N];
-  all_of<N>(dsc, d);
-  const rv rd = select(lane_lt(N), 1.0 / (dsc + select(lane_lt(N), rv(0.0), rv(1.0))), rv(0.0));
+  rv rd;
   rv C[N], M[N];
-  double size = 0.0;      // scale of the pivot test: the largest element of the scaled matrices
-  {
-    rv big = 0.0;      // largest |element| of the two scaled matrices in the own row
-    SS_UNROLL_FULL
-    for (int j = 0; j < N; ++j) {
-      const rv sc = rd * d[j];
-      const rv sj = g2[j] * sc;
-      C[j] = -(E[j] * sc);
-      M[j] = C[j] - 2.0 * sj;
-      big = r_max(big, r_max(r_abs(C[j]), r_abs(sj)));
-    }
-    static_for<0, N>([&](auto kc) { size = ss_max(size, bc<decltype(kc)::value>(big)); });
-    // rows beyond the order: identity (their pivots are never used, but keep the arithmetic finite)
-    SS_UNROLL_FULL
-    for (int j = 0; j < N; ++j) {
-      C[j] = select(lane_lt(N), C[j], rv(0.0));
-      M[j] = select(lane_lt(N), M[j], rv(0.0));
-    }
-  }
+  double size;
+  scaled_CM<N>(dsc, E, g2, C, M, size, rd);
   rv L[N], F[N];
   double rsL[N], rsF[N];
   bool ok = cholesky_rows<N>(C, L, rsL, 1.0e-14 * size);
@@ -301,7 +332,7 @@ SS_HD void eig_pre_rows(double* erec, long stride, const rv* E, const rv* g2, un
     return;
   }
   // own rows of F^T (M holds them scaled by the own pivot root) and of L^T
-  const rv rsF_own = own<N>(rsF), rsL_own = own<N>(rsL);
+  const rv rsF_own = own<N>(rsF);
   {
     rv FT[N], W[N];
     SS_UNROLL_FULL
@@ -323,26 +354,10 @@ SS_HD void eig_pre_rows(double* erec, long stride, const rv* E, const rv* g2, un
     mul<N, N, false, false>(FT, nullptr, L, W);
     store_rowmajor<N, N>(erec, stride, ER::W, W);
   }
-  {
-    rv DL[N];
-    SS_UNROLL_FULL
-    for (int j = 0; j < N; ++j) DL[j] = L[j] * dsc;
+  if constexpr (STORE_FACTORS) {
+    rv DL[N], X[N];
+    factor_rows<N>(dsc, C, L, rsL, DL, X);
     store_rowmajor<N, N>(erec, stride, ER::X, DL);
-  }
-  // -D L^-T: R = L^T is upper triangular with its rows on the lanes; R X = I by back substitution
-  {
-    rv X[N];
-    SS_UNROLL_FULL
-    for (int j = 0; j < N; ++j) X[j] = select(lane_eq(j), rv(1.0), rv(0.0));
-    static_for_down<1, N>([&](auto kc) {
-      constexpr int K = decltype(kc)::value;
-      // R(i, K) = C[K] * rsL_own for i <= K; x_K = (row K of X) / R(K, K) = (row K) * rsL[K]
-      const rv u = select(lane_lt(K), (C[K] * rsL_own) * rsL[K], rv(0.0));
-      row_fma<K, N>(X, X, -u);
-    });
-    const rv sc = -(dsc * rsL_own);
-    SS_UNROLL_FULL
-    for (int j = 0; j < N; ++j) X[j] = X[j] * sc;
     store_rowmajor<N, N>(erec, stride, ER::AX, X);
   }
 }
@@ -368,7 +383,11 @@ SS_HD void eig_pre_scalars(const LG& lg, double* erec, long stride, unsigned lon
   const RowGeom<NREG, NS> g(lg);
   rv E[N], g2[N];
   gamma_rows<URBAN, NREG, NS, LW>(lg, g, q, E, g2);
-  eig_pre_rows<N, LW>(erec, stride, E, g2, one_lane_units);
+#if defined(SS_LAYER16_FACTORS_FROM_RECORD)
+  eig_pre_rows<N, LW, true>(erec, stride, E, g2, one_lane_units);
+#else
+  eig_pre_rows<N, LW, false>(erec, stride, E, g2, one_lane_units);
+#endif
 }
 
 // Eigenvectors X = (D L) Y and (G1 - G2)^-1 X = (-D L^-T) Y from the factors and the rotations of the record
@@ -382,6 +401,46 @@ SS_HD void load_eigenvectors(const double* erec, long stride, rv* X, rv* AX) {
   load_rowmajor<N, N>(erec, stride, ER::AX, F);
   mul<N, N, false, false>(F, nullptr, Y, AX);
 }
+
+// The same with the factors recomputed from the layer's scalars (the solver: k_pre16 stores W only): Gamma rows,
+// C, its Cholesky factor, D L and -D L^-T - the arithmetic of eig_pre_rows, operation for operation, so the factor
+// is the one W was formed with
+template <bool URBAN, int NREG, int NS, bool LW>
+struct EigenvectorsFromScalars {
+  const LG* lg;
+  template <int N>
+  SS_HD void operator()(const double* erec, long stride, rv* X, rv* AX) const {
+    static_assert(N == NREG * NS, "order");
+    using ER = EigRec<N>;
+#if defined(SS_LAYER16_FACTORS_FROM_RECORD)
+    load_eigenvectors<N>(erec, stride, X, AX);
+#else
+    rv DL[N], AXr[N];
+    {
+      GammaScalars<NREG> q;
+      q.load(erec, stride, ER::G1);
+      const RowGeom<NREG, NS> g(*lg);
+      rv E[N], g2[N], C[N], M[N], L[N];
+      gamma_rows<URBAN, NREG, NS, LW>(*lg, g, q, E, g2);
+      const rv dsc = load_vec<N>(erec, stride, ER::VEC);
+      rv rd;
+      double size, rsL[N];
+      scaled_CM<N>(dsc, E, g2, C, M, size, rd);
+      cholesky_rows<N>(C, L, rsL, 1.0e-14 * size);       // (status 1: k_pre16 ran the same factorisation and it held)
+      factor_rows<N>(dsc, C, L, rsL, DL, AXr);
+    }
+    rv Y[N];
+    load_rowmajor<N, N>(erec, stride, ER::W, Y);
+    mul<N, N, false, false>(DL, nullptr, Y, X);
+    mul<N, N, false, false>(AXr, nullptr, Y, AX);
+#endif
+  }
+};
+// (the kernel-level entries: factors from the record)
+struct EigenvectorsFromRecord {
+  template <int N>
+  SS_HD void operator()(const double* erec, long stride, rv* X, rv* AX) const { load_eigenvectors<N>(erec, stride, X, AX); }
+};
 
 // Diffuse part (sw_eig :180-221, lw_eig :142-176): from eigenvalues, X and (G1 - G2)^-1 X of the
 // record to the eigenvector blocks G1, G2, lam, e = exp(-lam dz), LU(G1), C'_lower, C'_upper; R and T
@@ -459,8 +518,8 @@ SS_HD void diffuse_part(const rv* X, const rv* AX, const rv& ev_d, double dz, Di
 }
 
 // calc_matrices_lw_eig of a full problem: layer record of the unit from its eigen record
-template <int N>
-SS_HD void layer_lw(const double* erec, long stride, double* lrec) {
+template <int N, class LoadEV = EigenvectorsFromRecord>
+SS_HD void layer_lw(const double* erec, long stride, double* lrec, const LoadEV& load_ev = LoadEV{}) {
   using ER = EigRec<N>;
   using LR = LwRec<N>;
   const double dz = rec_elem_load(erec, stride, 1);
@@ -469,7 +528,7 @@ SS_HD void layer_lw(const double* erec, long stride, double* lrec) {
   Diffuse<N> df;
   {
     rv X[N], AX[N];
-    load_eigenvectors<N>(erec, stride, X, AX);
+    load_ev.template operator()<N>(erec, stride, X, AX);
     diffuse_part<N>(X, AX, load_vec<N>(erec, stride, ER::EV), dz, df, lrec, stride, LR::R, LR::T);
   }
   // Section 4 (:198-209): cb' and the source
@@ -507,8 +566,8 @@ SS_HD void layer_lw(const double* erec, long stride, double* lrec) {
 // calc_matrices_sw_eig of a full problem (N diffuse, D direct streams): R, T, S_up, S_dn of the layer
 // record from the eigen record; int_dir and E were written by the first pass of the layer kernel
 // (sw_direct_part), which also left mu, G0, G0^-1, exp(mu dz) of Gamma0 in the eigen record.
-template <int N, int D>
-SS_HD void layer_sw(const double* erec, long stride, double* lrec) {
+template <int N, int D, class LoadEV = EigenvectorsFromRecord>
+SS_HD void layer_sw(const double* erec, long stride, double* lrec, const LoadEV& load_ev = LoadEV{}) {
   using ER = EigRec<N>;
   using LR = SwRec<N, D>;
   const double dz = rec_elem_load(erec, stride, 1);
@@ -517,7 +576,7 @@ SS_HD void layer_sw(const double* erec, long stride, double* lrec) {
   Diffuse<N> df;
   {
     rv X[N], AX[N];
-    load_eigenvectors<N>(erec, stride, X, AX);
+    load_ev.template operator()<N>(erec, stride, X, AX);
     // Section 4 (:231-253) through the eigen-decomposition (see ss_layer_matrices.hpp): sources
     // s = g3 G0 (one column per direct eigenvalue), c = 2 (Lambda - mu^2)^-1 (D^-2 X)^T s,
     // p = X c, q = -mu ((G1 - G2)^-1 X) c, g3 = (p + q) / 2, g4 = (p - q) / 2

@@ -96,8 +96,10 @@ struct EmulBackend {
               ss::coop_eig_unit<NN, 1>(erec, ss::kRecStride, 0, L.eigen_fail ? L.eigen_fail + ss::kSlotOneLaneUnits : nullptr,
                                        L.cfg.decline_cooperative == 2);
               if (ss::r16_layer(NN, lw) && ss::rec_elem_load(erec, ss::kRecStride, ss::EigRec<NN>::STATUS) > 0.5) {
-                if (lw) ss::r16::layer_lw<NN>(erec, ss::kRecStride, L.lay + ss::rec_base(jlay, L.maxlay, ss::LwRec<NN>::NELEM, cu));
-                else ss::r16::layer_sw<NN, R>(erec, ss::kRecStride, L.lay + ss::rec_base(jlay, L.maxlay, ss::SwRec<NN, R>::NELEM, cu));
+                if (lw) ss::r16::layer_lw<NN>(erec, ss::kRecStride, L.lay + ss::rec_base(jlay, L.maxlay, ss::LwRec<NN>::NELEM, cu),
+                                              ss::r16::EigenvectorsFromScalars<U, R, NS, true>{&L.lg});
+                else ss::r16::layer_sw<NN, R>(erec, ss::kRecStride, L.lay + ss::rec_base(jlay, L.maxlay, ss::SwRec<NN, R>::NELEM, cu),
+                                              ss::r16::EigenvectorsFromScalars<U, R, NS, false>{&L.lg});
               }
             }
           }

@@ -43,8 +43,8 @@ def family_of(kernel, args):
     # k_layer16<N, D, LW>, k_column16 / k_down16 / k_pre16 as the one-lane kernels, k_eig_coop<N> serves
     # both spectral regions ("layer_both": half to each)
     a = [x.strip() for x in args.split(",")]
-    if kernel == "k_layer16":
-        return "lw_layer" if a[2] == "true" else "sw_layer"
+    if kernel == "k_layer16":       # <URBAN, NREG, NS, LW> since the second session of round 4, <N, D, LW> before
+        return "lw_layer" if a[3 if len(a) > 3 else 2] == "true" else "sw_layer"
     if kernel == "k_pre16" and len(a) > 3:          # k_pre16<URBAN, NREG, NS, LW>
         return "lw_layer" if a[3] == "true" else "sw_layer"
     if kernel in ("k_pre16", "k_eig_coop"):
