@@ -123,6 +123,9 @@ def edge_inputs(case, seed, kinds=EDGE_KINDS):
     return case
 
 
+SEED0 = int(os.environ.get("FUZZ_SEED0", "1000"))
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     edge = "--edge" in sys.argv
@@ -140,7 +143,7 @@ def main():
     ]
     results, worst = [], 0
     t0 = time.time()
-    for seed in range(1000, 1000 + nseeds):
+    for seed in range(SEED0, SEED0 + nseeds):
         for name, build in builders:
             case = build(seed)
             if edge:
