@@ -66,6 +66,8 @@ struct LwLayerIn {
   }
 };
 
+constexpr double kLwMaxSsa = 1.0 - 1.0e-12;
+
 template <bool URBAN, int NREG>
 SS_HD void lw_layer_props(const Launch& L, const LwLayerIn<URBAN, NREG>& r, LwLayerProps<URBAN, NREG>& p) {
   p.g = r.g;
@@ -76,6 +78,13 @@ SS_HD void lw_layer_props(const Launch& L, const LwLayerIn<URBAN, NREG>& r, LwLa
   p.vplanck = r.veg_planck;
   p.vaplanck = r.veg_air_planck;
   region_optics<NREG>(r.air_ext, r.air_ssa, p.g.veg_ext, p.vssa, p.od, p.ext_reg, p.ssa_reg);
+  // A longwave region that does not absorb at all (single-scattering albedo of exactly 1) is taken at 1 - 1e-12: a
+  // layer in which NO region absorbs has a singular Gamma1 + Gamma2, the symmetrised route declines it, and the
+  // general route that takes it over divides by zero - NaN for the whole column on the device, where the reference
+  // returns NaN or a finite number depending on the column (tools/fuzz_parity.py --edge, profiles/round4_edge_kinds.txt).
+  // With the clamp the unit stays on the symmetrised route and gets the limit; inputs below 1 - 1e-12 are untouched.
+  SS_UNROLL_FULL
+  for (int k = 0; k < NREG; ++k) p.ssa_reg[k] = ss_min(p.ssa_reg[k], kLwMaxSsa);
   p.planck_reg[0] = r.clear_air_planck;
   // (radsurf_forest_lw.F90:283-300)
   SS_UNROLL_FULL
